@@ -1,0 +1,250 @@
+"""Pin the CPU oracle (oracle/pta_oracle.py) to the reference.
+
+The fixtures in tests/golden/ are outputs of the UNMODIFIED reference run under stubs by
+oracle/gen_golden.py (which also reproduces the reference's shipped libstempo vector to
+5.6e-5/1.9e-4/3.8e-4 of RMS).  Tolerance here: 1e-12 relative RMS - the restatement performs
+the same float64 arithmetic up to BLAS/FFT summation order.
+"""
+import numpy as np
+import pytest
+
+from helpers import load, mjd_ld, relrms, shift_day, shift_s
+from oracle import pta_oracle as po
+
+TOL = 1e-12
+
+
+def _c1_case(tag):
+    z = load("c1_small.npz")
+    P = 3
+    mjd = [mjd_ld(z, tag, i) for i in range(P)]
+    locs = po.psr_locs_equatorial([{"RAJ": z[tag + "raj_hours"][i], "DECJ": z[tag + "decj_deg"][i]} for i in range(P)])
+    return z, P, mjd, locs
+
+
+@pytest.mark.parametrize("tag", ["raw_", "nudged_"])
+def test_c1_reference_test_recipe(tag):
+    """tests/test_against_libstempo.py:19-53, signal by signal."""
+    z, P, mjd, locs = _c1_case(tag)
+    # --- add_gwb(psrs, -14, 4.33, seed=123456)
+    grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd])
+    assert grid["Nf"] == int(z[tag + "Nf"])
+    ORF = po.gwb_orf(locs)
+    assert np.max(np.abs(ORF - z[tag + "ORF"])) < 1e-14
+    assert np.max(np.abs(po.hd_orf_closed_form(locs) - z[tag + "ORF"])) < 1e-14
+    M = np.linalg.cholesky(ORF)
+    assert np.max(np.abs(M - z[tag + "M"])) < 1e-14
+    w = po.gwb_draws(123456, P, grid["Nf"])
+    C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], -14, 4.33)
+    toa_s = [m.astype(np.float64).astype(float) * 86400 for m in mjd]
+    res_gw, Res = po.gwb_dt(grid, M, w, C, toa_s)
+    if tag == "nudged_":
+        Res_f = po.gwb_freq_series(M, w, C)
+        assert relrms(Res_f.real, z[tag + "Res_f"].real) < TOL and relrms(Res_f.imag, z[tag + "Res_f"].imag) < TOL
+        assert relrms(Res * grid["dt"], z[tag + "Res_t_used"]) < TOL
+    for a in range(P):
+        gw_day = res_gw[a] / 86400.0
+        assert relrms(gw_day, z[tag + "gwb"][a]) < TOL
+        mjd[a] = shift_day(mjd[a], z[tag + "gwb"][a])
+    # --- white noise + jitter share the seed (test_against_libstempo.py:30-34)
+    for a in range(P):
+        n = len(mjd[a])
+        z1, z2 = po.legacy_normals(54321 + a, [n, n])
+        sigma_s = z[f"{tag}err_us_{a}"] * 1e-6
+        wn = po.measurement_noise_dt(sigma_s, np.ones(n) * 1.0, np.ones(n) * 0.0, z1, z2)
+        assert relrms(wn, z[tag + "measurement_noise"][a]) < TOL
+        mjd[a] = shift_s(mjd[a], z[tag + "measurement_noise"][a])
+        epoch_of, ne, first, _ = po.quantize(mjd[a].astype(np.float64), dt=0.1)
+        (ze,) = po.legacy_normals(54321 + a, [ne])
+        jit = po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, np.log10(3e-7)), ze)
+        assert relrms(jit, z[tag + "jitter"][a]) < TOL
+        mjd[a] = shift_s(mjd[a], z[tag + "jitter"][a])
+    # --- red noise, libstempo convention
+    for a in range(P):
+        (zr,) = po.legacy_normals(12345 + a, [60])
+        rn = po.red_noise_dt(mjd[a], -15, 4.2, zr, components=30, libstempo_convention=True)
+        assert relrms(rn, z[tag + "red_noise"][a]) < TOL
+        mjd[a] = shift_s(mjd[a], z[tag + "red_noise"][a])
+    # --- cgw
+    for a in range(P):
+        cw = po.cgw_dt(mjd[a].astype(np.float64), locs[a, 1], locs[a, 0], gwtheta=np.pi / 2, gwphi=2.5, mc=1e9,
+                       dist=5.0, fgw=1e-8, phase0=0.5, psi=1.5, inc=np.pi / 4, pdist=1.0, tref=53000 * 86400)
+        assert relrms(cw, z[tag + "cw"][a]) < 1e-11
+
+
+def test_c1_libstempo_vector():
+    """the one golden vector the reference ships: the nudged (Nf=3000) stub run meets the reference's own
+    1e-3 bar (two-sided, per pulsar); the raw run (Nf=3001) is a different realisation."""
+    z = load("c1_small.npz")
+    gold = z["libstempo_residuals"]
+    for a in range(3):
+        assert relrms(z["nudged_residuals"][a], gold[a]) < 1e-3
+        assert relrms(z["raw_residuals"][a], gold[a]) > 0.1
+
+
+def test_c2_b1855_flags_and_epochs():
+    """notebook cell 9 recipe on the real, unsorted, 4-backend tim file."""
+    z = load("c2_b1855.npz")
+    mjd0 = z["mjd_hi"].astype(np.longdouble) + z["mjd_lo"].astype(np.longdouble)
+    toa_flags = z["backends"][z["flag_index"]]
+    n = len(mjd0)
+    for cg_tag, cg in (("cg1s_", 1.0 / 86400.0), ("cg01_", 0.1)):
+        mjd = mjd0.copy()
+        efacvec = po.flag_vector(toa_flags, z["efac_flags"], z["efac"], n)
+        equadvec = po.flag_vector(toa_flags, z["efac_flags"], 10 ** z["log10_equad"], n)
+        z1, z2 = po.legacy_normals(10660, [n, n])
+        wn = po.measurement_noise_dt(z["err_us"] * 1e-6, efacvec, equadvec, z1, z2)
+        assert relrms(wn, z[cg_tag + "measurement_noise"]) < TOL
+        mjd = shift_s(mjd, z[cg_tag + "measurement_noise"])
+        epoch_of, ne, first, _ = po.quantize(mjd.astype(np.float64), toa_flags, dt=cg)
+        assert ne == int(z[cg_tag + "n_epochs"])
+        (ze,) = po.legacy_normals(17763, [ne])
+        ecv = po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], toa_flags, z["ecorr_flags"])
+        jit = po.jitter_dt(epoch_of, ecv, ze)
+        assert relrms(jit, z[cg_tag + "jitter"]) < TOL
+        mjd = shift_s(mjd, z[cg_tag + "jitter"])
+        (zr,) = po.legacy_normals(19870, [60])
+        rn = po.red_noise_dt(mjd, float(z["rn_log10_amp"]), float(z["rn_gamma"]), zr, components=30)
+        assert relrms(rn, z[cg_tag + "red_noise"]) < 1e-11
+    # epoch structure of the ideal TOAs against the reference's own quantize_fast
+    epoch_of, ne, first, _ = po.quantize(mjd0.astype(np.float64), toa_flags, dt=0.1)
+    assert np.array_equal(epoch_of, z["cg01_epoch_of"]) and np.array_equal(toa_flags[first], z["cg01_aveflags"])
+
+
+def test_orf_basis_lmax4():
+    z = load("orf_basis.npz")
+    basis = np.array(po.correlated_basis(z["psr_locs"], int(z["lmax"])))
+    ref = z["basis"]
+    assert basis.shape == ref.shape
+    scale = np.max(np.abs(ref), axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(basis - ref) / scale) < 1e-11
+    assert np.max(np.abs(2 * np.sqrt(4 * np.pi) * ref[0] - po.hd_orf_closed_form(z["psr_locs"]))) < 1e-13
+
+
+def _variants():
+    z = load("variants.npz")
+    P = 4
+    mjd = [mjd_ld(z, "", i) for i in range(P)]
+    locs = po.psr_locs_equatorial([{"RAJ": z["raj_hours"][i], "DECJ": z["decj_deg"][i]} for i in range(P)])
+    return z, P, mjd, locs
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("gwb_turnover", dict(A=-14.2, g=13. / 3., seed=501, spec=dict(turnover=True, f0=3e-9, beta=1.2, power=2.0))),
+    ("gwb_userspec", dict(A=-14.2, g=13. / 3., seed=502, spec="userSpec")),
+    ("gwb_nocorr", dict(A=-14.5, g=3.9, seed=503, orf=dict(no_correlations=True))),
+    ("gwb_lmax2", dict(A=-14.5, g=13. / 3., seed=504, orf="clm2")),
+    ("gwb_grid", dict(A=-14.5, g=13. / 3., seed=505, grid=dict(npts=200, howml=4))),
+])
+def test_gwb_branches(tag, kw):
+    z, P, mjd, locs = _variants()
+    grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd], **kw.get("grid", {}))
+    assert grid["Nf"] == int(z[tag + "_Nf"])
+    orf = kw.get("orf", {})
+    ORF = po.gwb_orf(locs, clm=z["clm2"], lmax=2) if orf == "clm2" else po.gwb_orf(locs, **orf)
+    if tag + "_ORF" in z.files:
+        assert np.max(np.abs(ORF - z[tag + "_ORF"])) < 1e-13
+    spec = kw.get("spec", {})
+    spec = dict(userSpec=z["userSpec"]) if spec == "userSpec" else spec
+    C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], kw["A"], kw["g"], **spec)
+    w = po.gwb_draws(kw["seed"], P, grid["Nf"])
+    res_gw, _ = po.gwb_dt(grid, np.linalg.cholesky(ORF), w, C, [m.astype(np.float64) * 86400 for m in mjd])
+    for a in range(P):
+        assert relrms(res_gw[a] / 86400.0, z[tag][a]) < TOL
+
+
+def test_white_noise_branches():
+    z, P, mjd, locs = _variants()
+    backends = z["backends"]
+    for a in range(P):
+        n = len(mjd[a])
+        sig = z[f"err_us_{a}"] * 1e-6
+        fl = z[f"flag_{a}"]
+        z1, z2 = po.legacy_normals(600 + a, [n, n])
+        wn = po.measurement_noise_dt(sig, np.ones(n) * 1.3, np.ones(n) * 10 ** -6.3, z1, z2, tnequad=True)
+        assert relrms(wn, z["wn_tnequad"][a]) < TOL
+        z1, z2 = po.legacy_normals(610 + a, [n, n])
+        wn = po.measurement_noise_dt(sig, po.flag_vector(fl, backends, z["efac"], n),
+                                     po.flag_vector(fl, backends, 10 ** z["log10_equad"], n), z1, z2)
+        assert relrms(wn, z["wn_flags"][a]) < TOL
+        m2 = shift_s(mjd[a], z["wn_flags"][a])
+        epoch_of, ne, first, _ = po.quantize(m2.astype(np.float64), fl, dt=0.1)
+        assert ne < n  # multi-TOA epochs
+        (ze,) = po.legacy_normals(620 + a, [ne])
+        jit = po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], fl, backends), ze)
+        assert relrms(jit, z["jitter_flags"][a]) < TOL
+        epoch_of, ne, first, _ = po.quantize(mjd[a].astype(np.float64), dt=0.1)
+        (ze,) = po.legacy_normals(630 + a, [ne])
+        assert relrms(po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, -6.4), ze), z["jitter_scalar"][a]) < TOL
+
+
+def test_red_noise_default_convention():
+    z, P, mjd, locs = _variants()
+    for a in range(P):
+        (zr,) = po.legacy_normals(640 + a, [30])
+        assert relrms(po.red_noise_dt(mjd[a], -13.8, 3.3, zr, components=15), z["rn_default"][a]) < 1e-11
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("cgw_evolve", dict(pdist=1.3, psrTerm=True, evolve=True)),
+    ("cgw_phase_approx", dict(pdist=0.9, psrTerm=True, evolve=False, phase_approx=True)),
+    ("cgw_mono", dict(pdist=1.1, psrTerm=True, evolve=False, phase_approx=False)),
+    ("cgw_earth_only", dict(pdist=1.0, psrTerm=False, evolve=True)),
+    ("cgw_pphase", dict(pphase=2.1, psrTerm=True, evolve=True)),
+    ("cgw_mono_earth", dict(pdist=1.0, psrTerm=False, evolve=False, phase_approx=False)),
+])
+def test_cgw_branches(tag, kw):
+    z, P, mjd, locs = _variants()
+    base = dict(gwtheta=1.1, gwphi=4.0, mc=3e9, dist=40.0, fgw=2.2e-8, phase0=1.3, psi=0.4, inc=1.0, tref=53000 * 86400)
+    for a in range(P):
+        cw = po.cgw_dt(mjd[a].astype(np.float64), locs[a, 1], locs[a, 0], **base, **kw)
+        assert relrms(cw, z[tag][a]) < 1e-11
+
+
+def test_c3_mini_full_stack():
+    z = load("c3_mini.npz")
+    P = 6
+    mjd = [mjd_ld(z, "", i) for i in range(P)]
+    locs = po.psr_locs_equatorial([{"RAJ": z["raj_hours"][i], "DECJ": z["decj_deg"][i]} for i in range(P)])
+    for a in range(P):
+        n = len(mjd[a])
+        z1, z2 = po.legacy_normals(10660 + a, [n, n])
+        wn = po.measurement_noise_dt(z[f"err_us_{a}"] * 1e-6, np.ones(n) * z["efac"][a],
+                                     np.ones(n) * 10 ** z["log10_equad"][a], z1, z2)
+        assert relrms(wn, z["measurement_noise"][a]) < TOL
+        mjd[a] = shift_s(mjd[a], z["measurement_noise"][a])
+        epoch_of, ne, first, _ = po.quantize(mjd[a].astype(np.float64), dt=0.1)
+        (ze,) = po.legacy_normals(17763 + a, [ne])
+        assert relrms(po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, z["log10_ecorr"][a]), ze), z["jitter"][a]) < TOL
+        mjd[a] = shift_s(mjd[a], z["jitter"][a])
+        (zr,) = po.legacy_normals(19870 + a, [60])
+        assert relrms(po.red_noise_dt(mjd[a], z["rn_log10_A"][a], z["rn_gamma"][a], zr), z["red_noise"][a]) < 1e-11
+        mjd[a] = shift_s(mjd[a], z["red_noise"][a])
+    grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd])
+    assert grid["Nf"] == int(z["Nf"])
+    ORF = po.hd_orf_closed_form(locs)
+    assert np.max(np.abs(ORF - z["ORF"])) < 1e-14
+    w = po.gwb_draws(16672, P, grid["Nf"])
+    C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], float(z["gw_log10_A"]), float(z["gw_gamma"]))
+    res_gw, _ = po.gwb_dt(grid, np.linalg.cholesky(ORF), w, C, [m.astype(np.float64) * 86400 for m in mjd])
+    for a in range(P):
+        assert relrms(res_gw[a] / 86400.0, z["gwb"][a]) < TOL
+
+
+def test_td_oracle_covariance_matches_synthesis_statistics():
+    """TD-mode covariance is the covariance of the reference's RN+WN+ECORR synthesis:
+    checked analytically, E[dt dt^T] = F phi F^T + N."""
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.uniform(53000, 56000, 40)) * 86400.0
+    epoch_of, ne, first, _ = po.quantize(t / 86400.0, dt=30.0)
+    sig2 = rng.uniform(1e-14, 4e-14, 40)
+    ec = np.full(ne, 2e-7)
+    Cm = po.td_covariance(t, -13.5, 3.0, 10, sig2, epoch_of, ec)
+    assert np.allclose(Cm, Cm.T, rtol=0, atol=1e-25)
+    L = np.linalg.cholesky(Cm)
+    assert np.max(np.abs(L @ L.T - Cm)) < 1e-12 * np.max(np.abs(Cm))
+    F, fr = po.fourier_design_matrix(t, nmodes=10)
+    phi = po.red_noise_prior(fr, -13.5, 3.0, t.max() - t.min())
+    U = (epoch_of[:, None] == np.arange(ne)[None, :]).astype(float)
+    ref = F @ np.diag(phi) @ F.T + np.diag(sig2) + (U * ec ** 2) @ U.T
+    assert np.max(np.abs(Cm - ref)) < 1e-12 * np.max(np.abs(ref))
