@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Headline benchmark: realisations/sec, 68 pulsars x 5000 TOAs, GWB + RN + WN (EFAC/EQUAD + ECORR), fp64.
+
+    python bench.py --gpus N --steps K --warmup W [--batch R]
+
+A "step" is one pass of the hot path over one batch of R realisations of the whole array, every Gaussian deviate
+drawn on chip, inputs resident in HBM (ReplicaEngine.generate: pta_engine_rn_coef -> pta_gwb_idft_rng ->
+pta_gwb_mix -> pta_engine_synth).  N > 1: launched by torch.distributed.run, one rank per GPU; realisations are
+independent, so rank g generates realisations [g*R*K .. ) of the same seeded stream (weak scaling, no data-path
+collective; the north_star's gather of the residual arrays to rank 0 is timed separately and reported as
+`gather_ms`, not folded into the step).  Rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline      the dominant kernel of the step against its bound (algorithmic units per launch / measured
+                launch time; HBM peak 8 TB/s from MI355X_MICROARCH.md, fp64 matrix peak 78.6 TFLOP/s = AMD's
+                public MI355X figure, cross-checked by the in-library microbenchmark)
+  kernels       per-kernel times of one step (HIP events on the launch stream)
+  cpu_baseline  the CPU oracle (a NumPy port of the reference's algebra, oracle/pta_oracle.py) timed on this
+                host for one realisation of the same workload, with the reference's dense-U ECORR
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GW_LOG10_A = -14.6733          # noise_dicts/ng15_dict.json "gw_log10_A" 
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix figure (not in the local guide)
+
+
+def headline_array(P=68, N=5000, seed=68):
+    """Config 3 of BASELINE.json as synthetic inputs: isotropic sky, sorted uniform MJDs over
+    15 yr, 0.5 us errors, per-pulsar power-law RN (one pulsar without, like J0614-3329), EFAC/EQUAD/ECORR."""
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    rng = np.random.default_rng(seed)
+    raj = rng.uniform(0, 24, P)
+    decj = np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
+    psrs = []
+    for a in range(P):
+        mjd = np.sort(rng.uniform(53000, 58478, N))
+        psr = SimulatedPulsar(toas=ArrayTOAs(mjd, 0.5), name=f"J{a:04d}+0000", loc={"RAJ": float(raj[a]), "DECJ": float(decj[a])})
+        make_ideal(psr)
+        psrs.append(psr)
+    rn_A = [float(x) for x in rng.uniform(-15.0, -13.0, P)]
+    rn_g = [float(x) for x in rng.uniform(1.0, 5.0, P)]
+    if P > 7:
+        rn_A[7] = rn_g[7] = None
+    noise = dict(rn_log10_A=rn_A, rn_gamma=rn_g, efac=[float(x) for x in rng.uniform(0.9, 1.2, P)],
+                 log10_equad=[float(x) for x in rng.uniform(-7.0, -6.0, P)],
+                 log10_ecorr=[float(x) for x in rng.uniform(-7.0, -6.0, P)], gw_log10_A=GW_LOG10_A)
+    return psrs, noise
+
+
+def build_engine(P, N, seed):
+    from pta_replicator_amd.engine import ReplicaEngine
+    psrs, noise = headline_array(P, N)
+    eng = ReplicaEngine(psrs, seed=seed)
+    eng.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"])
+    eng.set_jitter(log10_ecorr=noise["log10_ecorr"], coarsegrain=0.1)
+    eng.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"], components=30)
+    eng.set_gwb(noise["gw_log10_A"], 13. / 3.)
+    eng.prepare()
+    return eng, psrs, noise
+
+
+def cpu_baseline(psrs, noise, repeats=1):
+    """One realisation of the same workload through the CPU oracle, the way the reference spends its time:
+    everything (ORF, design matrices, dense ECORR U) rebuilt per call.  Returns dict for the JSON line."""
+    from oracle import pta_oracle as po
+    P = len(psrs)
+    mjd = [np.asarray(p.toas.get_mjds().value, dtype=np.float64) for p in psrs]
+    tdb = [p.toas.table["tdbld"] for p in psrs]
+    sig = [np.asarray(p.toas.get_errors().to("s").value) for p in psrs]
+    locs = po.psr_locs_equatorial([p.loc for p in psrs])
+    parts = {}
+
+    def run(dense_u):
+        t0 = time.perf_counter()
+        grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd])
+        ORF = po.gwb_orf(locs)                      # pair loop in Python, like spharmORFbasis.correlated_basis
+        M = np.linalg.cholesky(ORF)
+        w = po.gwb_draws(16672, P, grid["Nf"])
+        C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], noise["gw_log10_A"], 13. / 3.)
+        po.gwb_dt(grid, M, w, C, [m * 86400 for m in mjd])
+        t1 = time.perf_counter()
+        for a in range(P):
+            if noise["rn_log10_A"][a] is not None:
+                (zr,) = po.legacy_normals(19870 + a, [60])
+                po.red_noise_dt(tdb[a], noise["rn_log10_A"][a], noise["rn_gamma"][a], zr)
+        t2 = time.perf_counter()
+        for a in range(P):
+            n = len(mjd[a])
+            z1, z2 = po.legacy_normals(10660 + a, [n, n])
+            po.measurement_noise_dt(sig[a], np.ones(n) * noise["efac"][a], np.ones(n) * 10 ** noise["log10_equad"][a], z1, z2)
+        t3 = time.perf_counter()
+        for a in range(P):
+            epoch_of, ne, first, _ = po.quantize(mjd[a], dt=0.1)
+            (ze,) = po.legacy_normals(17763 + a, [ne])
+            ecv = po.jitter_ecorr_vector(ne, first, noise["log10_ecorr"][a])
+            if dense_u:   # white_noise.py:37-39,182: dense N x E indicator matrix and matvec
+                U = np.zeros((len(mjd[a]), ne), "d")
+                U[np.arange(len(mjd[a])), epoch_of] = 1
+                np.dot(U * ecv, ze)
+            else:
+                po.jitter_dt(epoch_of, ecv, ze)
+        t4 = time.perf_counter()
+        return dict(gwb=t1 - t0, rn=t2 - t1, wn=t3 - t2, ecorr=t4 - t3, total=t4 - t0)
+
+    dense = min((run(True) for _ in range(repeats)), key=lambda d: d["total"])
+    gather = run(False)
+    return {"value": 1.0 / dense["total"], "unit": "realisations/s", "cores": 1, "kind": "port",
+            "sample": f"1 realisation of the same {P} psr x {len(mjd[0])} TOA workload (GWB+RN+EFAC/EQUAD+ECORR) through "
+                      f"oracle/pta_oracle.py, reference-style dense-U ECORR; NumPy BLAS threads = default, Python loop single-threaded",
+            "seconds": {k: round(v, 4) for k, v in dense.items()},
+            "value_ecorr_as_gather": 1.0 / gather["total"],
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=960, help="realisations per step per GPU")
+    ap.add_argument("--psr", type=int, default=68)
+    ap.add_argument("--toa", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="also time the gather of the residual arrays to rank 0")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from pta_replicator_amd import _lib, device as dv
+    eng, psrs, noise = build_engine(args.psr, args.toa, seed=20260921)
+    R, K, W = args.batch, args.steps, args.warmup
+    out = dv.empty((R, eng.n_toa))
+    base = rank * R * (K + W)   # disjoint realisation ranges per rank: same stream, any GPU count
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        eng.generate(R, r0=base + i * R, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.generate(R, r0=base + (W + i) * R, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel times of one step: HIP events on the stream the kernels are launched on ----
+    kern = {}
+    s = dv.stream_ptr()
+    ws = eng.workspace(R)
+    npts, Nf, P = eng.plan.gw_npts, eng.grid["Nf"], eng.P
+
+    def timed(name, fn, reps=3):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fn()
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        kern[name] = ev[0].elapsed_time(ev[1]) / reps
+
+    import ctypes
+    timed("pta_engine_rn_coef", lambda: _lib.call("pta_engine_rn_coef", eng.seed, 0, R, P, eng.K, dv.ptr(eng.d_amp), dv.ptr(ws["coef"]), s))
+    timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_T), eng.ldt, npts, dv.ptr(ws["G0"]), npts, s))
+    timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s))
+    timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
+
+    gather_ms = None
+    if args.gather and world > 1:
+        from pta_replicator_amd.distributed import gather_to_rank0
+        barrier()
+        tg = time.perf_counter()
+        gather_to_rank0(out)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel ----
+    # algorithmic work per realisation: bytes = 8 * sum N_a (the residual array written once);
+    # flops of the GWB frequency->time stage as the reference writes it = 4 P^2 Nf (M @ w) + 5 n log2 n P (ifft, n = 2Nf-2)
+    n_fft = 2 * Nf - 2
+    alg_bytes = 8.0 * eng.n_toa * R
+    alg_flops_gwb = (4.0 * P * P * Nf + 5.0 * n_fft * np.log2(n_fft) * P) * R
+    exe_flops_gwb = 2.0 * (R * P) * (2.0 * (Nf - 2)) * npts       # what the pruned-DFT GEMM actually executes
+    dom = max(("pta_gwb_idft_rng", "pta_engine_synth"), key=lambda k: kern[k])
+    if dom == "pta_engine_synth":
+        ach = alg_bytes / (kern[dom] * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None}
+    else:
+        ach = alg_flops_gwb / (kern[dom] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                "executed_tflops": exe_flops_gwb / (kern[dom] * 1e-3) / 1e12}
+    roof["avg_launch_ms"] = kern[dom]
+    other = "pta_engine_synth" if dom != "pta_engine_synth" else "pta_gwb_idft_rng"
+    roof["also"] = {"kernel": "pta_engine_synth", "bound": "hbm", "achieved": alg_bytes / (kern["pta_engine_synth"] * 1e-3) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s"} if other == "pta_engine_synth" else \
+                   {"kernel": "pta_gwb_idft_rng", "bound": "mfma", "achieved": alg_flops_gwb / (kern["pta_gwb_idft_rng"] * 1e-3) / 1e12,
+                    "executed_tflops": exe_flops_gwb / (kern["pta_gwb_idft_rng"] * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+
+    micro = {}
+    try:
+        res = ctypes.c_double(0.0)
+        for kind, name in ((0, "fp64_mfma_tflops"), (1, "fp64_fma_tflops"), (2, "hbm_write_TBps"), (4, "normals_T_per_s")):
+            _lib.call("pta_microbench", kind, 1 << 30, 2000 if kind in (0, 1) else (20 if kind == 2 else 200), ctypes.byref(res))
+            micro[name] = round(res.value, 3)
+    except Exception as e:  # pragma: no cover
+        micro["error"] = str(e)
+
+    line = {
+        "metric": "realizations/sec, 68 psr x 5000 TOAs GWB+RN+WN", "value": world * R * K / elapsed, "unit": "realizations/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.psr} pulsars x {args.toa} TOAs synthetic array (BASELINE.json config 3 geometry): HD GWB + per-pulsar "
+                               f"power-law RN (30 components) + EFAC/EQUAD + ECORR, on-chip Philox draws, {R} realisations per step per GPU",
+                   "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
+        "roofline": roof, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
+    }
+    if gather_ms is not None:
+        line["gather_ms"] = gather_ms
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(psrs, noise)
+        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+/*
+ * pta_replicator_amd — C ABI of the MI355X (gfx950) stochastic-injection hot path.
+ *
+ * The reference (bencebecsy/pta_replicator) is pure Python with no FFI layer of its own
+ * (SURVEY.md §8b); this header therefore defines the boundary a maintainer would bind with
+ * ctypes (INTEGRATION.md shows the stub).  Each entry point cites the reference code it
+ * replaces as file:line under /root/reference/pta_replicator/.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no torch / C++ types.
+ *  - Every `double*` / `int32_t*` is a DEVICE pointer to contiguous memory owned by the
+ *    caller (e.g. torch.Tensor.data_ptr()) unless the parameter name ends in `_host`.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream). Calls are
+ *    asynchronous on that stream; no allocation, no synchronisation inside.
+ *  - Return 0 on success, a negative PTA_E_* code otherwise; pta_last_error() gives the
+ *    thread-local message. No exceptions cross the boundary.
+ *  - Batches: R realisations are the leading axis; `ld_*` are row strides in elements.
+ *    `accumulate` = 0 overwrites `out`, 1 adds into it.
+ *  - Everything is IEEE binary64, like the reference (it casts PINT's longdouble columns to
+ *    float64 before any arithmetic: red_noise.py:123, :287).
+ */
+#ifndef PTA_REPLICATOR_AMD_H
+#define PTA_REPLICATOR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTA_ABI_VERSION 1
+
+#define PTA_OK 0
+#define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
+#define PTA_E_HIP (-2)     /* HIP runtime error; message carries hipGetErrorString */
+#define PTA_E_NOTPD (-3)   /* reserved: matrix not positive definite (see `info` of pta_potrf_batched) */
+
+/* ---------------------------------------------------------------- library ---------- */
+int pta_abi_version(void);
+const char *pta_last_error(void);
+/* number of CUs / wavefront size / gcnArchName of the current HIP device */
+int pta_device_info(int *cu_count, int *wavefront, char *arch, int arch_len);
+
+/* ---------------------------------------------------------------- RNG -------------- */
+/* Throughput-mode draws. The reference consumes NumPy's global legacy stream
+ * (red_noise.py:119,127,176,238-240; white_noise.py:80,105-109,155,182); on the device every
+ * deviate is Philox-4x32-10(key = seed, counter = (pair, stream, realisation)) + Box-Muller.
+ * stream ids: (kind << 24) | pulsar, kind = 1 GWB, 2 RN, 3 WN, 4 ECORR, 5 TD.           */
+
+/* Known-answer access to the raw generator: out[i] = 4 x u32 of
+ * Philox4x32-10(counter = ctr[i][0..3], key = key[0..1]).  ctr/key/out are device u32.   */
+int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int n, uint32_t *out, void *stream);
+
+/* Dump the normals the fused kernels would use, in the layout the replay kernels read:
+ *   interleave = 1: z0[r*ld + 2p] = first, z0[r*ld + 2p + 1] = second deviate of pair p (z1 unused)
+ *   interleave = 0: z0[r*ld + p] = first, z1[r*ld + p] = second deviate of pair p
+ * for pairs p in [0, npairs), realisations r0 .. r0+R-1.                                   */
+int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t stream_id, int npairs, int interleave,
+                        double *z0, double *z1, int64_t ld, void *stream);
+
+/* ---------------------------------------------------------------- red noise -------- */
+/* Fourier design matrix, transposed: Ft[c*N + i] = column c of F for TOA i.
+ * Replaces create_fourier_design_matrix_red (red_noise.py:36-103).
+ *   arg = ((2 pi) * (t[i] - t_ref)) * f[k] + phase[k]        (phase may be NULL = 0)
+ *   cos_first = 0 (default convention, t_ref = 0): c = 2k sin, c = 2k+1 cos   (:98-101)
+ *   cos_first = 1 (libstempo convention, t_ref = t[0]): c = 2k cos, c = 2k+1 sin (:92-96) */
+int pta_rn_basis(const double *t, int N, double t_ref, const double *f, const double *phase, int nmodes,
+                 int cos_first, double *Ft, int64_t ldf, void *stream);
+
+/* out[r*ld_out + i] (+)= sum_c Ft[c*ldf + i] * coef[r*ld_coef + c],  c < K.
+ * Replaces dt = F @ (sqrt(prior) * randn) (red_noise.py:127-128); coef = sqrt(prior)*z.    */
+int pta_rn_synth(const double *Ft, int64_t ldf, int N, int K, const double *coef, int64_t ld_coef, int R, double *out,
+                 int64_t ld_out, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- white noise ------ */
+/* out[r,i] (+)= (efac[i]*sigma[i])*z1[r,i] + (tnequad ? equad[i] : efac[i]*equad[i])*z2[r,i]
+ * Replaces add_measurement_noise's arithmetic (white_noise.py:105-109).                    */
+int pta_wn(const double *sigma, const double *efac, const double *equad, int N, int tnequad, const double *z1,
+           const double *z2, int64_t ld_z, int R, double *out, int64_t ld_out, int accumulate, void *stream);
+
+/* Greedy epoch bucketing on the HOST (realisation independent). Replaces quantize_fast
+ * (white_noise.py:7-44) without the dense U: epoch_of_host[i] = column of U holding TOA i;
+ * first_index_host[e] = first (earliest) TOA of epoch e, whose flag labels the epoch (:35).
+ * order_host = np.argsort(times) to reproduce the reference's tie order exactly, or NULL for a
+ * stable sort.  first_index_host must have room for N entries.                             */
+int pta_quantize_epochs(const double *times_host, int N, double dt, const int64_t *order_host,
+                        int32_t *epoch_of_host, int32_t *first_index_host, int *n_epochs);
+
+/* out[r,i] (+)= ecorr_epoch[epoch_of[i]] * z[r*ld_z + epoch_of[i]]
+ * Replaces dt = (U*ecorrvec) @ randn(E) (white_noise.py:182): a gather, not an N x E matvec. */
+int pta_ecorr(const int32_t *epoch_of, const double *ecorr_epoch, int N, int E, const double *z, int64_t ld_z, int R,
+              double *out, int64_t ld_out, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- ORF -------------- */
+/* locs[a*2+0] = phi (RA, rad), locs[a*2+1] = theta (colatitude, rad) (red_noise.py:205-223). */
+
+/* lmax = 0, clm = [sqrt(4 pi)] fast path: orf[a*P+b] = 2*HD(zeta_ab), 2 on zeta == 0.
+ * Equals red_noise.py:224-226 with the defaults.                                           */
+int pta_orf_hd(const double *locs, int P, double *orf, void *stream);
+
+/* basis[(k*P + a)*P + b], k = l*l + (m + l): spharmORFbasis.correlated_basis
+ * (spharmORFbasis.py:385-434 and callees :14-382). lmax <= 8.                              */
+int pta_orf_basis(const double *locs, int P, int lmax, double *basis, void *stream);
+
+/* orf = 2 * sum_k clm[k] * basis[k]  (red_noise.py:225-226). clm is a device array.        */
+int pta_orf_combine(const double *basis, const double *clm, int nbasis, int P, double *orf, void *stream);
+
+/* In-place lower Cholesky of B row-major n x n matrices (reads the lower triangle, zeroes the
+ * strict upper one - np.linalg.cholesky's result, red_noise.py:235).  info[b] = 0, or j+1 if the
+ * leading minor of order j+1 is not positive definite (LAPACK convention).  Blocked right-looking:
+ * LDS panel factorisation + fp64 MFMA (v_mfma_f64_16x16x4_f64) trailing update.             */
+int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
+
+/* debug/validation knob: 1 (default) = MFMA GEMM inside potrf / mix / trmm, 0 = VALU reference GEMM */
+int pta_set_gemm_algo(int algo);
+
+/* ---------------------------------------------------------------- GWB -------------- */
+/* The reference's chain (red_noise.py:238-287): w -> M@w -> *sqrt(C), zero DC/Nyquist -> Hermitian
+ * pack to n = 2Nf-2 -> real(ifft)/dt -> crop [i0, i0+npts) -> linear interpolation onto TOAs.
+ * Only npts of the n time samples are ever used, and mixing with M commutes with the DFT, so the
+ * device evaluates   G0 = W . T   (pruned inverse DFT as a dense fp64 GEMM on MFMA, T the twiddle
+ * matrix with sqrt(C)/(n dt) folded in), then G = M . G0 on the npts grid, then interpolates.  */
+
+/* T[(c*(Nf-2) + k-1)*ldt + jj], c = 0 (cos) / 1 (sin), k = 1..Nf-2, jj < npts:
+ *   T0 =  (2/(n dt)) sqrtC[k] cos(2 pi (i0+jj) k / n),   T1 = -(2/(n dt)) sqrtC[k] sin(...)
+ * (red_noise.py:265-279, :285 with i0 = 10).                                              */
+int pta_gwb_twiddle(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *T, int64_t ldt, void *stream);
+
+/* G0[m*ldg + jj] = sum_k wre[m,k] T0[k-1,jj] + wim[m,k] T1[k-1,jj];  w interleaved (re,im),
+ * row stride ldw doubles, w[m*ldw + 2k] = Re w[m,k].  algo: 0 = VALU reference kernel,
+ * 1 = MFMA kernel.                                                                          */
+int pta_gwb_idft(const double *w, int64_t ldw, int M, int Nf, const double *T, int64_t ldt, int npts, double *G0,
+                 int64_t ldg, int algo, void *stream);
+
+/* Same with w generated on chip: row m = r*P + a uses stream (GWB, a) of realisation r0 + r,
+ * pair k -> (Re, Im) of w[a,k] (red_noise.py:238-240).                                     */
+int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *T, int64_t ldt, int npts,
+                     double *G0, int64_t ldg, void *stream);
+
+/* G[r,a,:] = sum_b Mchol[a,b] G0[r,b,:]  (the M@w of red_noise.py:268, applied after the DFT). */
+int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream);
+
+/* jlo[i] = last j with ut[j] <= toa_s[i], clamped to [0, npts-2] (numpy.interp's bracket, which
+ * scipy.interpolate.interp1d(kind="linear") delegates to; red_noise.py:286-287).           */
+int pta_gwb_bracket(const double *ut, int npts, const double *toa_s, int N, int32_t *jlo, void *stream);
+
+/* out[r*ld_out + i] (+)= slope*(toa_s[i] - ut[j]) + G[j],  j = jlo[i], G row = (r, psr_of_toa[i]).
+ * scale multiplies the result (1/86400 gives the day-valued delay of red_noise.py:292).     */
+int pta_gwb_interp(const double *G, int64_t ldg, int P, int npts, const double *ut, const double *toa_s,
+                   const int32_t *psr_of_toa, const int32_t *jlo, int N, int R, double scale, double *out,
+                   int64_t ld_out, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- CGW -------------- */
+/* Continuous-wave residual (deterministic.py:97-163). par_host[PTA_CGW_NPAR] holds the scalar
+ * prefactors the Python wrapper computes exactly as deterministic.py:51-109 does:
+ *  0 tref  1 w0  2 phase0(orbital)  3 w053  4 fac1  5 fac2  6 fac3  7 incfac1  8 incfac2
+ *  9 cos2psi  10 sin2psi  11 fplus  12 fcross  13 pd*(1-cosMu)  14 mode (0 evolve, 1 phase_approx,
+ *  2 monochromatic)  15 psrTerm (0/1)  16 omega_p (phase_approx, :126)  17 phase0 + fac2*(w053 -
+ *  omega_p^(-5/3)) (phase_approx, :130)                                                      */
+#define PTA_CGW_NPAR 18
+int pta_cgw(const double *mjd, int N, const double *par_host, double *out, int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- fused engine ----- */
+/* One pass that writes R whole-array realisations: out[r, i] = RN + GWB + WN + ECORR + det,
+ * every deviate generated on chip (throughput mode).  All arrays are device pointers; any
+ * signal whose pointer is NULL is skipped.                                                  */
+typedef struct {
+  int32_t n_toa;              /* sum of N_a */
+  int32_t n_psr;              /* P */
+  int32_t rn_k;               /* 2*components (0 = no red noise) */
+  int32_t gw_npts;            /* 0 = no GWB */
+  int32_t tnequad;
+  int32_t reserved;
+  const int32_t *psr_of_toa;  /* [n_toa] pulsar index of each TOA (TOAs of a pulsar are contiguous) */
+  const int32_t *idx_in_psr;  /* [n_toa] index of the TOA inside its pulsar (WN pair index) */
+  const double *Ft;           /* [rn_k x ldf] design matrix rows for the concatenated TOAs */
+  int64_t ldf;
+  const double *rn_coef;      /* [R x n_psr x rn_k] sqrt(prior)*z, from pta_engine_rn_coef */
+  const double *gw_G;         /* [R x n_psr x gw_npts] mixed GWB grid series */
+  const double *gw_ut;        /* [gw_npts] */
+  const double *toa_s;        /* [n_toa] */
+  const int32_t *gw_jlo;      /* [n_toa] */
+  const double *wn_a;         /* [n_toa] efac*sigma */
+  const double *wn_b;         /* [n_toa] efac*equad (t2equad) or equad (tnequad) */
+  const int32_t *epoch_of;    /* [n_toa] epoch index inside the pulsar */
+  const double *ecorr_toa;    /* [n_toa] ecorr of the TOA's epoch (0 = none) */
+  const double *det;          /* [n_toa] realisation-independent deterministic delay (e.g. CGW) */
+} pta_engine_plan;
+
+/* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
+int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, void *stream);
+
+int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
+                     void *stream);
+
+/* ---------------------------------------------------------------- TD mode ---------- */
+/* Dense time-domain path named by BASELINE.json's north_star (no counterpart in the reference,
+ * which never forms an N_toa x N_toa object: SURVEY.md §0.2, App. A.1).
+ * C[i,j] = sum_c phi[c] Ft[c,i] Ft[c,j] + (i==j) sigma2[i] + (epoch_of[i]==epoch_of[j]) ecorr2[i]
+ * i.e. the covariance of the reference's RN (red_noise.py:98-101,126-128) + WN/ECORR
+ * (white_noise.py:105-109,182) synthesis.  Only the lower triangle (col <= row) is written - that is
+ * all pta_potrf_batched reads.  HBM-write bound: 8 bytes per element of the triangle.        */
+int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const double *phi, const double *sigma2,
+                        const int32_t *epoch_of, const double *ecorr2, double *C, int64_t ldc, void *stream);
+
+/* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
+ * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or
+ * pta_rng_fill_normal(stream (TD, pulsar)) in throughput mode.                              */
+int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld_z, int R, double *out, int64_t ld_out,
+                int accumulate, void *stream);
+
+/* ---------------------------------------------------------------- fp64 GEMM -------- */
+/* C[b] = alpha * A[b] * op(B[b]) + beta * C[b], row-major, batch `batch` with element strides.
+ * A element (m,k) = A[m*lda + k*ska] (ska = 2 reads the real or imaginary plane of interleaved
+ * complex rows); transB = 0: B is [K x N]; 1: B is [N x K].  lower_only = 1 touches only col <= row
+ * (SYRK).  algo 0 = VALU reference kernel, 1 = v_mfma_f64_16x16x4_f64 kernel.                */
+int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
+              const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
+              int64_t strideA, int64_t strideB, int64_t strideC, int algo, void *stream);
+
+/* ---------------------------------------------------------------- microbenchmarks -- */
+/* Measure the roofline denominators on the device the library runs on (bench.py):
+ * kind 0: fp64 MFMA (v_mfma_f64_16x16x4_f64) TFLOP/s, 1: fp64 FMA TFLOP/s,
+ * 2: HBM write GB/s over `bytes`, 3: HBM copy GB/s, 4: Philox+Box-Muller G normals/s.      */
+int pta_microbench(int kind, int64_t bytes, int iters, double *result_host);
+
+/* self-test of the fp64 MFMA lane layout used by the GEMM kernels: returns 0 when a 16x16x4
+ * product with asymmetric operands matches the scalar result on the device.                */
+int pta_selftest_mfma_f64(double *max_err_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTA_REPLICATOR_AMD_H */

@@ -325,12 +325,14 @@ def gen_c3_mini(ref):
     out.update(rn_log10_A=rn_A, rn_gamma=rn_g, efac=efac, log10_equad=l10eq, log10_ecorr=l10ec,
                gw_log10_A=np.array(-14.6733), gw_gamma=np.array(13. / 3.))
     seed_efac_equad, seed_jitter, seed_red, seed_gwb = 10660, 17763, 19870, 16672   # notebook cell 8
+    # GWB first, as in the reference's own test (tests/test_against_libstempo.py:25): the frequency grid is then
+    # built from the ideal TOAs, which is also how the batched engine defines a realisation
+    with Capture() as cap:
+        ref.red_noise.add_gwb(psrs, log10_amplitude=-14.6733, spectral_index=13. / 3., seed=seed_gwb)
     for ii, psr in enumerate(psrs):
         ref.white_noise.add_measurement_noise(psr, efac=float(efac[ii]), log10_equad=float(l10eq[ii]), seed=seed_efac_equad + ii)
         ref.white_noise.add_jitter(psr, log10_ecorr=float(l10ec[ii]), coarsegrain=0.1, seed=seed_jitter + ii)
         ref.red_noise.add_red_noise(psr, float(rn_A[ii]), float(rn_g[ii]), components=30, seed=seed_red + ii)
-    with Capture() as cap:
-        ref.red_noise.add_gwb(psrs, log10_amplitude=-14.6733, spectral_index=13. / 3., seed=seed_gwb)
     for k in ("measurement_noise", "jitter", "red_noise", "gwb"):
         out[k] = np.array([sig(p, k) for p in psrs])
     out["residuals"] = np.array([p.toas.residuals_s() for p in psrs])

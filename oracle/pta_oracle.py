@@ -388,14 +388,13 @@ def hd_orf_closed_form(psr_locs):
     phi, th = psr_locs[:, 0], psr_locs[:, 1]
     arg = (np.sin(th)[:, None] * np.sin(th)[None, :] * np.cos(phi[:, None] - phi[None, :])
            + np.cos(th)[:, None] * np.cos(th)[None, :])
-    arg = np.clip(arg, -1.0, 1.0)
-    c = np.cos(np.arccos(arg))
-    x = (1.0 - c) / 2.0
+    zeta = np.arccos(np.clip(arg, -1.0, 1.0))
+    same = (phi[:, None] == phi[None, :]) & (th[:, None] == th[None, :])
+    zeta[same] = 0.0
+    x = (1.0 - np.cos(zeta)) / 2.0
     with np.errstate(divide="ignore", invalid="ignore"):
         orf = 2.0 * (0.5 - x / 4.0 + 1.5 * x * np.log(x))
-    same = (phi[:, None] == phi[None, :]) & (th[:, None] == th[None, :])
-    orf[same] = 2.0
-    orf[(~same) & (x == 0.0)] = 1.0
+    orf[zeta == 0.0] = 2.0    # zeta == 0 branch with pulsar-term doubling (spharmORFbasis.py:311,327-329)
     return orf
 
 

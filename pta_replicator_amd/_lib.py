@@ -1,0 +1,99 @@
+"""ctypes binding of libpta_replicator_amd.so (the C ABI declared in include/pta_replicator_amd.h).
+
+There is no CPU fallback: if the shared library is missing the import fails loudly, and every entry
+point raises ``PtaError`` with the library's own message on a non-zero return code.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+# torch must own the HIP runtime of the process: it ships its own libamdhip64.so.7 and our library must
+# bind to that same copy (same SONAME) so that tensors' device pointers and streams are valid inside it.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpta_replicator_amd.so")
+
+
+class PtaError(RuntimeError):
+    """A call into libpta_replicator_amd.so returned a PTA_E_* code."""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build the HIP library first (python -m pta_replicator_amd.build, or "
+        "__graft_entry__.build()). pta_replicator_amd has no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_P = c_void_p  # device / host raw pointers are passed as integers
+
+
+class EnginePlan(ctypes.Structure):
+    """pta_engine_plan (include/pta_replicator_amd.h)."""
+    _fields_ = [
+        ("n_toa", c_int32), ("n_psr", c_int32), ("rn_k", c_int32), ("gw_npts", c_int32), ("tnequad", c_int32),
+        ("reserved", c_int32),
+        ("psr_of_toa", _P), ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
+        ("gw_ut", _P), ("toa_s", _P), ("gw_jlo", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
+        ("ecorr_toa", _P), ("det", _P),
+    ]
+
+
+_SIGNATURES = {
+    "pta_abi_version": (c_int, []),
+    "pta_last_error": (c_char_p, []),
+    "pta_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "pta_rng_philox_raw": (c_int, [_P, _P, c_int, _P, _P]),
+    "pta_rng_fill_normal": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, _P, _P, c_int64, _P]),
+    "pta_rn_basis": (c_int, [_P, c_int, c_double, _P, _P, c_int, c_int, _P, c_int64, _P]),
+    "pta_rn_synth": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_wn": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_quantize_epochs": (c_int, [_P, c_int, c_double, _P, _P, _P, POINTER(c_int)]),
+    "pta_ecorr": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_orf_hd": (c_int, [_P, c_int, _P, _P]),
+    "pta_orf_basis": (c_int, [_P, c_int, c_int, _P, _P]),
+    "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
+    "pta_potrf_batched": (c_int, [_P, c_int, c_int, _P, _P]),
+    "pta_set_gemm_algo": (c_int, [c_int]),
+    "pta_gwb_twiddle": (c_int, [_P, c_int, c_int, c_int, c_double, _P, c_int64, _P]),
+    "pta_gwb_idft": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_gwb_idft_rng": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, c_int64, c_int, _P, c_int64, _P]),
+    "pta_gwb_mix": (c_int, [_P, c_int, _P, c_int, c_int, c_int64, _P, _P]),
+    "pta_gwb_bracket": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "pta_gwb_interp": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_double, _P, c_int64, c_int, _P]),
+    "pta_cgw": (c_int, [_P, c_int, _P, _P, c_int, _P]),
+    "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, _P]),
+    "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
+    "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
+    "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_double, _P, c_int64, c_int64, _P, c_int64, c_double, _P, c_int64,
+                          c_int, c_int, c_int64, c_int64, c_int64, c_int, _P]),
+    "pta_microbench": (c_int, [c_int, c_int64, c_int, POINTER(c_double)]),
+    "pta_selftest_mfma_f64": (c_int, [POINTER(c_double)]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+for _name, (_res, _args) in _SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = the .so is stale: rebuild
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.pta_abi_version() != 1:
+    raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
+
+
+def last_error():
+    msg = lib.pta_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise PtaError(f"{what or 'libpta_replicator_amd'} failed (code {rc}): {last_error()}")
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on error."""
+    check(getattr(lib, name)(*args), name)

@@ -1,0 +1,197 @@
+// fp64 GEMM on the CDNA4 matrix cores: C = alpha * A * op(B) + beta * C.
+//
+// The dense products of the path all come through here: the pruned inverse DFT of the GWB chain
+// (W . T, red_noise.py:275-285), the ORF mix on the coarse grid (M . G0, red_noise.py:268), the
+// trailing-submatrix update of the blocked Cholesky (red_noise.py:235 and TD mode) and TD mode's L . Z.
+//
+// v_mfma_f64_16x16x4_f64 lane layout (cdna_hip_programming.md §3, verified at run time by
+// pta_selftest_mfma_f64):  A operand: lane l holds A[i = l & 15][k = l >> 4]
+//                          B operand: lane l holds B[k = l >> 4][j = l & 15]
+//                          C/D:       acc[reg] is C[row = (l >> 4) + 4*reg][col = l & 15]
+//
+// Tiling: 64x64 C tile per 256-thread workgroup (4 waves as 2x2, each 32x32 = 2x2 MFMA tiles),
+// K staged through LDS in slabs of 16.  Both operand slabs are stored K-major with a row pitch of
+// 80 doubles (== 16 mod 32), which makes the ds_read_b64 fragment reads bank-conflict free: the 32
+// lanes of a group read k in {kk, kk+1} x 16 consecutive doubles, i.e. dword offsets
+// 2*(k*80 + i) that cover all 64 banks exactly once.
+#include "pta_common.h"
+#include "pta_mfma.h"
+
+#define GBM 64
+#define GBN 64
+#define GBK 16
+#define GLD 80
+
+template <bool BT>
+__global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double alpha, const double *__restrict__ A,
+                                                    int64_t lda, int64_t ska, const double *__restrict__ B, int64_t ldb,
+                                                    double beta, double *__restrict__ C, int64_t ldc, int lower_only,
+                                                    int64_t sA, int64_t sB, int64_t sC) {
+  const int bm = blockIdx.y, bn = blockIdx.x;
+  if (lower_only && bn * GBN > bm * GBM + (GBM - 1)) return;  // tile entirely above the diagonal
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  __shared__ double As[GBK][GLD];
+  __shared__ double Bs[GBK][GLD];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = bm * GBM, n0 = bn * GBN;
+  pta_f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < K; k0 += GBK) {
+    {  // A slab: 64 rows x 16 k, 4 consecutive k per thread
+      int row = t >> 2, kq = (t & 3) * 4;
+      int gm = m0 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int gk = k0 + kq + j;
+        As[kq + j][row] = (gm < M && gk < K) ? A[(int64_t)gm * lda + (int64_t)gk * ska] : 0.0;
+      }
+    }
+    if (BT) {  // B given as [N x K]: element (k, n) at B[n*ldb + k]
+      int col = t >> 2, kq = (t & 3) * 4;
+      int gn = n0 + col;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int gk = k0 + kq + j;
+        Bs[kq + j][col] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+      }
+    } else {  // B given as [K x N]: coalesced along n
+      int kr = t >> 4, nq = (t & 15) * 4;
+      int gk = k0 + kr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int gn = n0 + nq + j;
+        Bs[kr][nq + j] = (gk < K && gn < N) ? B[(int64_t)gk * ldb + gn] : 0.0;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = As[kk + (l >> 4)][wm * 32 + i * 16 + (l & 15)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Bs[kk + (l >> 4)][wn * 32 + j * 16 + (l & 15)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 32 + i * 16 + pta_mfma_row(l, r);
+        int col = n0 + wn * 32 + j * 16 + pta_mfma_col(l);
+        if (row < M && col < N && (!lower_only || col <= row)) {
+          int64_t o = (int64_t)row * ldc + col;
+          double v = alpha * acc[i][j][r];
+          C[o] = (beta == 0.0) ? v : v + beta * C[o];
+        }
+      }
+}
+
+// plain VALU kernel: one thread per C element.  Cross-check for the MFMA kernel and the fallback
+// for operand shapes too small to fill a tile.
+template <bool BT>
+__global__ void k_dgemm_valu(int M, int N, int K, double alpha, const double *__restrict__ A, int64_t lda, int64_t ska,
+                             const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
+                             int lower_only, int64_t sA, int64_t sB, int64_t sC) {
+  int col = blockIdx.x * blockDim.x + threadIdx.x;
+  int row = blockIdx.y;
+  if (col >= N || row >= M || (lower_only && col > row)) return;
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  double acc = 0.0;
+  for (int k = 0; k < K; ++k) {
+    double b = BT ? B[(int64_t)col * ldb + k] : B[(int64_t)k * ldb + col];
+    acc = fma(A[(int64_t)row * lda + (int64_t)k * ska], b, acc);
+  }
+  int64_t o = (int64_t)row * ldc + col;
+  double v = alpha * acc;
+  C[o] = (beta == 0.0) ? v : v + beta * C[o];
+}
+
+int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
+                     const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
+                     int64_t sA, int64_t sB, int64_t sC, int algo, hipStream_t stream) {
+  PTA_REQUIRE(A && B && C, PTA_E_ARG, "pta_dgemm: NULL argument");
+  PTA_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, PTA_E_ARG, "pta_dgemm: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  if (algo == 0) {
+    PTA_REQUIRE(M <= 65535, PTA_E_ARG, "pta_dgemm: VALU kernel supports M <= 65535 (got %d)", M);
+    dim3 g(pta_cdiv(N, 128), M, batch);
+    if (transB)
+      hipLaunchKernelGGL(k_dgemm_valu<true>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    else
+      hipLaunchKernelGGL(k_dgemm_valu<false>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+  } else {
+    PTA_REQUIRE(pta_cdiv(M, GBM) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
+    dim3 g(pta_cdiv(N, GBN), pta_cdiv(M, GBM), batch);
+    if (transB)
+      hipLaunchKernelGGL(k_dgemm_mfma<true>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    else
+      hipLaunchKernelGGL(k_dgemm_mfma<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+  }
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+extern "C" int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
+                         const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
+                         int64_t strideA, int64_t strideB, int64_t strideC, int algo, void *stream) {
+  return pta_dgemm_launch(transB, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, batch, strideA, strideB,
+                          strideC, algo, pta_stream(stream));
+}
+
+// ---- run-time check of the lane layout assumed above ------------------------------------------
+__global__ void k_selftest_mfma(const double *__restrict__ A, const double *__restrict__ B, double *__restrict__ C) {
+  int l = threadIdx.x;
+  pta_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+  acc = pta_mfma_f64(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], acc);
+  for (int r = 0; r < 4; ++r) C[pta_mfma_row(l, r) * 16 + pta_mfma_col(l)] = acc[r];
+}
+
+extern "C" int pta_selftest_mfma_f64(double *max_err_host) {
+  PTA_REQUIRE(max_err_host, PTA_E_ARG, "pta_selftest_mfma_f64: NULL argument");
+  double hA[64], hB[64], hC[256], *dA, *dB, *dC;
+  for (int i = 0; i < 16; ++i)
+    for (int k = 0; k < 4; ++k) hA[i * 4 + k] = 1.0 + 0.37 * i - 0.11 * k * k + 0.013 * i * k;  // asymmetric on purpose
+  for (int k = 0; k < 4; ++k)
+    for (int j = 0; j < 16; ++j) hB[k * 16 + j] = -0.5 + 0.21 * j + 0.77 * k - 0.031 * j * k * k;
+  PTA_HIP(hipMalloc(&dA, sizeof(hA)));
+  PTA_HIP(hipMalloc(&dB, sizeof(hB)));
+  PTA_HIP(hipMalloc(&dC, sizeof(hC)));
+  PTA_HIP(hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice));
+  PTA_HIP(hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dC);
+  PTA_LAUNCH_CHECK();
+  PTA_HIP(hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost));
+  (void)hipFree(dA);
+  (void)hipFree(dB);
+  (void)hipFree(dC);
+  double worst = 0.0;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      double ref = 0.0;
+      for (int k = 0; k < 4; ++k) ref = fma(hA[i * 4 + k], hB[k * 16 + j], ref);
+      double e = fabs(hC[i * 16 + j] - ref);
+      if (e > worst) worst = e;
+    }
+  *max_err_host = worst;
+  if (worst > 1e-12) {
+    pta_set_error("fp64 MFMA lane layout self-test failed: max |err| = %g", worst);
+    return PTA_E_HIP;
+  }
+  return PTA_OK;
+}

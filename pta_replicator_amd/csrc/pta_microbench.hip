@@ -1,0 +1,119 @@
+// Roofline denominators measured on the device itself (bench.py / DESIGN.md): the local guide gives HBM
+// and fp32/bf16 peaks but no fp64 figures.
+#include "pta_common.h"
+#include "pta_mfma.h"
+#include "pta_rng.h"
+
+__global__ __launch_bounds__(256) void k_mb_mfma(double *out, int iters) {
+  pta_f64x4 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = pta_mfma_f64(a, b, acc[i]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void k_mb_fma(double *out, int iters) {
+  double x[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) x[i] = 1.0 + i * 1e-3 + threadIdx.x * 1e-9;
+  double a = 1.0000001, b = 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = fma(x[i], a, b);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += x[i];
+  if (s == 123.456) out[0] = s;
+}
+
+__global__ void k_mb_write(double2 *out, int64_t n2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  double2 v = make_double2(1.0, 2.0);
+  for (; i < n2; i += stride) out[i] = v;
+}
+
+__global__ void k_mb_copy(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n2) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n2; i += stride) out[i] = in[i];
+}
+
+__global__ __launch_bounds__(256) void k_mb_rng(double *out, int iters) {
+  double s = 0.0;
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    double z0, z1;
+    pta_normal_pair(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p, z0, z1);
+    s += z0 * z1;
+  }
+  if (s == 123.456) out[0] = s;
+}
+
+extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result_host) {
+  PTA_REQUIRE(result_host && iters > 0, PTA_E_ARG, "pta_microbench: bad argument");
+  int dev = 0;
+  PTA_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  PTA_HIP(hipGetDeviceProperties(&prop, dev));
+  const int cus = prop.multiProcessorCount;
+  hipEvent_t e0, e1;
+  PTA_HIP(hipEventCreate(&e0));
+  PTA_HIP(hipEventCreate(&e1));
+  double *buf = nullptr, *buf2 = nullptr;
+  int64_t nbytes = (kind == 2 || kind == 3) ? bytes : 4096;
+  PTA_REQUIRE(nbytes >= 4096, PTA_E_ARG, "pta_microbench: bytes too small");
+  PTA_HIP(hipMalloc(&buf, nbytes));
+  if (kind == 3) PTA_HIP(hipMalloc(&buf2, nbytes));
+  float ms = 0.f;
+  double work = 0.0;
+  const int reps = (kind == 2 || kind == 3) ? iters : 3;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0 = warm-up
+    PTA_HIP(hipEventRecord(e0, 0));
+    for (int rep = 0; rep < reps; ++rep) {
+      switch (kind) {
+        case 0:
+          hipLaunchKernelGGL(k_mb_mfma, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * 8 * 4 * iters * 8.0 * 2048.0 * reps;  // waves * mfma * flop
+          break;
+        case 1:
+          hipLaunchKernelGGL(k_mb_fma, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * 8 * 256 * iters * 16.0 * 2.0 * reps;
+          break;
+        case 2:
+          hipLaunchKernelGGL(k_mb_write, dim3(cus * 8), dim3(256), 0, 0, (double2 *)buf, nbytes / 16);
+          work = (double)nbytes * reps;
+          break;
+        case 3:
+          hipLaunchKernelGGL(k_mb_copy, dim3(cus * 8), dim3(256), 0, 0, (const double2 *)buf2, (double2 *)buf, nbytes / 16);
+          work = 2.0 * (double)nbytes * reps;
+          break;
+        case 4:
+          hipLaunchKernelGGL(k_mb_rng, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * 8 * 256 * iters * 2.0 * reps;  // normals
+          break;
+        default:
+          pta_set_error("pta_microbench: unknown kind %d", kind);
+          return PTA_E_ARG;
+      }
+    }
+    PTA_HIP(hipEventRecord(e1, 0));
+    PTA_HIP(hipEventSynchronize(e1));
+    PTA_HIP(hipEventElapsedTime(&ms, e0, e1));
+  }
+  PTA_LAUNCH_CHECK();
+  (void)hipFree(buf);
+  if (buf2) (void)hipFree(buf2);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *result_host = work / (ms * 1e-3) / 1e12;  // T(flop|byte|normal)/s
+  return PTA_OK;
+}

@@ -1,0 +1,177 @@
+// ORF evaluation (spharmORFbasis.py) and the batched blocked Cholesky (np.linalg.cholesky at
+// red_noise.py:235; the same factorisation serves TD mode's N_toa x N_toa covariances).
+#include "pta_common.h"
+#include "pta_orf.h"
+
+// ---- ORF ---------------------------------------------------------------------------------------
+__global__ void k_orf_hd(const double *__restrict__ locs, int P, double *__restrict__ orf) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  int a = blockIdx.y;
+  if (b >= P) return;
+  orf[(int64_t)a * P + b] = pta_orf_hd(locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1]);
+}
+
+extern "C" int pta_orf_hd(const double *locs, int P, double *orf, void *stream) {
+  PTA_REQUIRE(locs && orf, PTA_E_ARG, "pta_orf_hd: NULL argument");
+  PTA_REQUIRE(P > 0 && P <= 65535, PTA_E_ARG, "pta_orf_hd: P=%d", P);
+  hipLaunchKernelGGL(k_orf_hd, dim3(pta_cdiv(P, 64), P), dim3(64), 0, pta_stream(stream), locs, P, orf);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+// one thread per (a <= b, l): all 2l+1 real-form values, mirrored into both triangles
+// (correlated_basis, spharmORFbasis.py:385-434)
+__global__ void k_orf_basis(const double *__restrict__ locs, int P, double *__restrict__ basis) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  int a = blockIdx.y;
+  int l = blockIdx.z;
+  if (b >= P || b < a) return;
+  double v[2 * PTA_ORF_LMAX + 1];
+  pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], v);
+  for (int mi = 0; mi <= 2 * l; ++mi) {
+    int64_t k = (int64_t)l * l + mi;
+    basis[(k * P + a) * P + b] = v[mi];
+    basis[(k * P + b) * P + a] = v[mi];
+  }
+}
+
+extern "C" int pta_orf_basis(const double *locs, int P, int lmax, double *basis, void *stream) {
+  PTA_REQUIRE(locs && basis, PTA_E_ARG, "pta_orf_basis: NULL argument");
+  PTA_REQUIRE(P > 0 && P <= 65535, PTA_E_ARG, "pta_orf_basis: P=%d", P);
+  PTA_REQUIRE(lmax >= 0 && lmax <= PTA_ORF_LMAX, PTA_E_ARG, "pta_orf_basis: lmax=%d unsupported (0..%d)", lmax, PTA_ORF_LMAX);
+  hipLaunchKernelGGL(k_orf_basis, dim3(pta_cdiv(P, 64), P, lmax + 1), dim3(64), 0, pta_stream(stream), locs, P, basis);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+__global__ void k_orf_combine(const double *__restrict__ basis, const double *__restrict__ clm, int nbasis, int64_t PP,
+                              double *__restrict__ orf) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PP) return;
+  double s = 0.0;
+  for (int k = 0; k < nbasis; ++k) s = s + clm[k] * basis[(int64_t)k * PP + i];  // sum(...) of red_noise.py:225
+  orf[i] = s * 2.0;                                                              // :226
+}
+
+extern "C" int pta_orf_combine(const double *basis, const double *clm, int nbasis, int P, double *orf, void *stream) {
+  PTA_REQUIRE(basis && clm && orf, PTA_E_ARG, "pta_orf_combine: NULL argument");
+  PTA_REQUIRE(P > 0 && nbasis > 0, PTA_E_ARG, "pta_orf_combine: P=%d nbasis=%d", P, nbasis);
+  int64_t PP = (int64_t)P * P;
+  hipLaunchKernelGGL(k_orf_combine, dim3(pta_cdiv(PP, 256)), dim3(256), 0, pta_stream(stream), basis, clm, nbasis, PP, orf);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+// ---- blocked Cholesky ---------------------------------------------------------------------------
+// Right-looking, block size 64, row-major, lower.  Per block column:
+//   k_potf2 : the 64x64 diagonal block is factored in LDS by one workgroup per matrix
+//   k_trsm  : the panel below it is solved against L11^T, 64 rows per workgroup, L11 and the tile in LDS
+//   SYRK    : the trailing submatrix update A22 -= L21 L21^T runs on the fp64 MFMA GEMM (pta_gemm.hip)
+#define CH_NB 64
+#define CH_LD 65
+
+__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, int k0, int nb, int32_t *__restrict__ info) {
+  __shared__ double S[CH_NB][CH_LD];
+  __shared__ double djj;
+  double *M = A + (int64_t)blockIdx.x * n * n;
+  const int t = threadIdx.x;
+  for (int e = t; e < nb * nb; e += 256) {
+    int i = e / nb, c = e % nb;
+    S[i][c] = (c <= i) ? M[(int64_t)(k0 + i) * n + (k0 + c)] : 0.0;
+  }
+  for (int j = 0; j < nb; ++j) {
+    __syncthreads();
+    if (t == 0) {
+      double d = S[j][j];
+      if (!(d > 0.0) && info[blockIdx.x] == 0) info[blockIdx.x] = k0 + j + 1;  // LAPACK: leading minor j+1 not PD
+      d = sqrt(d);
+      S[j][j] = d;
+      djj = d;
+    }
+    __syncthreads();
+    double inv = 1.0 / djj;
+    for (int i = j + 1 + t; i < nb; i += 256) S[i][j] = S[i][j] * inv;
+    __syncthreads();
+    int rem = nb - j - 1;
+    for (int e = t; e < rem * rem; e += 256) {
+      int i = j + 1 + e / rem, c = j + 1 + e % rem;
+      if (c <= i) S[i][c] = fma(-S[i][j], S[c][j], S[i][c]);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < nb * nb; e += 256) {
+    int i = e / nb, c = e % nb;
+    M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int k0, int nb) {
+  __shared__ double L[CH_NB][CH_LD];
+  __shared__ double X[CH_NB][CH_LD];
+  double *M = A + (int64_t)blockIdx.y * n * n;
+  const int t = threadIdx.x;
+  const int r0 = k0 + nb + blockIdx.x * CH_NB;
+  const int rows = min(CH_NB, n - r0);
+  for (int e = t; e < nb * nb; e += 256) {
+    int i = e / nb, c = e % nb;
+    L[i][c] = M[(int64_t)(k0 + i) * n + (k0 + c)];
+  }
+  for (int e = t; e < rows * nb; e += 256) {
+    int i = e / nb, c = e % nb;
+    X[i][c] = M[(int64_t)(r0 + i) * n + (k0 + c)];
+  }
+  // X <- X L^{-T}: column sweep
+  for (int j = 0; j < nb; ++j) {
+    __syncthreads();
+    if (t < rows) X[t][j] = X[t][j] / L[j][j];
+    __syncthreads();
+    int rem = nb - j - 1;
+    for (int e = t; e < rows * rem; e += 256) {
+      int i = e / rem, c = j + 1 + e % rem;
+      X[i][c] = fma(-X[i][j], L[c][j], X[i][c]);
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < rows * nb; e += 256) {
+    int i = e / nb, c = e % nb;
+    M[(int64_t)(r0 + i) * n + (k0 + c)] = X[i][c];
+  }
+}
+
+__global__ void k_zero_upper(double *__restrict__ A, int n) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (c < n && c > r) A[(int64_t)blockIdx.z * n * n + (int64_t)r * n + c] = 0.0;
+}
+
+static int g_gemm_algo = 1;
+extern "C" int pta_set_gemm_algo(int algo) {
+  g_gemm_algo = algo ? 1 : 0;
+  return PTA_OK;
+}
+int pta_get_gemm_algo() { return g_gemm_algo; }
+
+extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream) {
+  PTA_REQUIRE(A && info, PTA_E_ARG, "pta_potrf_batched: NULL argument");
+  PTA_REQUIRE(n > 0 && n <= 65535 && B > 0 && B <= 65535, PTA_E_ARG, "pta_potrf_batched: n=%d B=%d", n, B);
+  hipStream_t s = pta_stream(stream);
+  PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
+  const int64_t nn = (int64_t)n * n;
+  for (int k0 = 0; k0 < n; k0 += CH_NB) {
+    int nb = (n - k0 < CH_NB) ? (n - k0) : CH_NB;
+    hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, s, A, n, k0, nb, info);
+    PTA_LAUNCH_CHECK();
+    int rows = n - k0 - nb;
+    if (rows > 0) {
+      hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, k0, nb);
+      PTA_LAUNCH_CHECK();
+      const double *L21 = A + (int64_t)(k0 + nb) * n + k0;
+      double *A22 = A + (int64_t)(k0 + nb) * n + (k0 + nb);
+      int rc = pta_dgemm_launch(1, rows, rows, nb, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
+      if (rc != PTA_OK) return rc;
+    }
+  }
+  hipLaunchKernelGGL(k_zero_upper, dim3(pta_cdiv(n, 256), n, B), dim3(256), 0, s, A, n);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}

@@ -1,0 +1,52 @@
+// Throughput-mode draws: raw Philox access (known-answer tests) and the buffer fill that dumps the
+// exact normals the fused kernels generate in-register.
+#include "pta_common.h"
+#include "pta_rng.h"
+
+__global__ void k_philox_raw(const uint32_t *__restrict__ ctr, const uint32_t *__restrict__ key, int n,
+                             uint32_t *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pta_u32x4 c = {ctr[4 * i + 0], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3]};
+  pta_u32x4 v = pta_philox4x32_10(c, key[0], key[1]);
+  out[4 * i + 0] = v.x;
+  out[4 * i + 1] = v.y;
+  out[4 * i + 2] = v.z;
+  out[4 * i + 3] = v.w;
+}
+
+extern "C" int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int n, uint32_t *out, void *stream) {
+  PTA_REQUIRE(ctr && key && out && n > 0, PTA_E_ARG, "pta_rng_philox_raw: bad argument");
+  hipLaunchKernelGGL(k_philox_raw, dim3(pta_cdiv(n, 256)), dim3(256), 0, pta_stream(stream), ctr, key, n, out);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+__global__ void k_fill_normal(uint64_t seed, uint64_t r0, uint32_t stream_id, int npairs, int interleave,
+                              double *__restrict__ z0, double *__restrict__ z1, int64_t ld) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (p >= npairs) return;
+  double a, b;
+  pta_normal_pair(seed, r0 + (uint64_t)r, stream_id, (uint32_t)p, a, b);
+  if (interleave) {
+    double2 v = make_double2(a, b);
+    *reinterpret_cast<double2 *>(z0 + (int64_t)r * ld + 2 * (int64_t)p) = v;
+  } else {
+    z0[(int64_t)r * ld + p] = a;
+    z1[(int64_t)r * ld + p] = b;
+  }
+}
+
+extern "C" int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t stream_id, int npairs, int interleave,
+                                   double *z0, double *z1, int64_t ld, void *stream) {
+  PTA_REQUIRE(z0 && (interleave || z1), PTA_E_ARG, "pta_rng_fill_normal: NULL output");
+  PTA_REQUIRE(R > 0 && npairs > 0, PTA_E_ARG, "pta_rng_fill_normal: R=%d npairs=%d", R, npairs);
+  PTA_REQUIRE(ld >= (interleave ? 2 * (int64_t)npairs : (int64_t)npairs), PTA_E_ARG, "pta_rng_fill_normal: ld too small");
+  PTA_REQUIRE(!interleave || (ld % 2 == 0 && ((uintptr_t)z0 % 16) == 0), PTA_E_ARG,
+              "pta_rng_fill_normal: interleaved output needs even ld and 16-byte alignment");
+  hipLaunchKernelGGL(k_fill_normal, dim3(pta_cdiv(npairs, 256), R), dim3(256), 0, pta_stream(stream), seed, r0, stream_id,
+                     npairs, interleave, z0, z1, ld);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}

@@ -1,0 +1,425 @@
+"""ReplicaEngine: R independent realisations of a whole pulsar-timing array per call, on one MI355X.
+
+The reference produces one realisation per sequence of ``add_*`` calls (a Python loop over pulsars, one pass
+through PINT per call).  For ensembles the realisation-independent work - Fourier design matrices
+(red_noise.py:36-103), epoch maps (white_noise.py:7-44), ORF + Cholesky (red_noise.py:200-235), spectrum
+(:243-265), the DFT twiddle matrix, interpolation brackets (:286-287), CGW waveforms (deterministic.py:13-185) -
+is done once in ``prepare()``; ``generate()`` then runs three kernels per batch:
+
+  pta_engine_rn_coef   60 red-noise coefficients per (realisation, pulsar)
+  pta_gwb_idft_rng     pruned inverse DFT of on-chip draws, fp64 MFMA      + pta_gwb_mix (ORF mix, MFMA)
+  pta_engine_synth     fused RN + GWB-interp + EFAC/EQUAD + ECORR + deterministic -> out[R, sum N_a]
+
+Draws are counter-based (Philox-4x32-10 keyed by seed; counter = pair, stream, realisation), so realisation r
+is the same numbers whatever the batch size, launch geometry or number of GPUs.  ``replay()`` pushes
+caller-supplied draws (e.g. NumPy's legacy stream in the reference's order, or ``dump_draws()``) through the
+per-signal kernels - that is the parity path.
+
+Realisations are defined on the IDEAL TOAs.  The reference applies each signal's delay to the TOAs before the
+next ``add_*`` reads them (adjust_TOAs in every function); the induced difference is O(delay * f) ~ 1e-12
+relative (SURVEY.md §7 "hard parts" ii) and is the stated tolerance floor of batched-vs-sequential parity.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, device as dv
+from . import deterministic as det
+from . import red_noise as rn
+from . import white_noise as wn
+from ._position import ra_dec
+from .constants import DAY_IN_SEC, YEAR_IN_SEC
+
+STREAM_GWB, STREAM_RN, STREAM_WN, STREAM_ECORR, STREAM_TD = 1, 2, 3, 4, 5
+
+
+def stream_id(kind, pulsar):
+    return ((kind << 24) | (pulsar & 0xFFFFFF)) & 0xFFFFFFFF
+
+
+class ReplicaEngine:
+    def __init__(self, psrs, seed=0):
+        self.psrs = list(psrs)
+        self.P = len(self.psrs)
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.names = [p.name for p in self.psrs]
+        # ideal TOAs: float64 MJD (GWB/ECORR/CGW read get_mjds, red_noise.py:287, white_noise.py:158,
+        # deterministic.py:98) and float64(tdbld)*86400 (RN, red_noise.py:123)
+        self.mjd = [np.asarray(p.toas.get_mjds().value, dtype=np.float64) for p in self.psrs]
+        self.tdb_s = [np.array(p.toas.table["tdbld"], dtype="float64") * DAY_IN_SEC for p in self.psrs]
+        self.sigma_s = [np.asarray(p.toas.get_errors().to("s").value, dtype=np.float64) for p in self.psrs]
+        self.counts = np.array([len(m) for m in self.mjd])
+        self.off = np.concatenate([[0], np.cumsum(self.counts)]).astype(np.int64)
+        self.n_toa = int(self.off[-1])
+        self._rn = None
+        self._wn = None
+        self._ec = None
+        self._gw = None
+        self._det = None
+        self._prepared = False
+
+    # ---------------------------------------------------------------- configuration -------------
+    def set_red_noise(self, log10_amplitude, spectral_index, components=30, libstempo_convention=False):
+        """per-pulsar power-law red noise; entries may be None to skip a pulsar (red_noise.py:106-135)."""
+        self._rn = dict(A=list(np.broadcast_to(np.asarray(log10_amplitude, dtype=object), (self.P,))),
+                        g=list(np.broadcast_to(np.asarray(spectral_index, dtype=object), (self.P,))),
+                        components=int(components), libstempo=bool(libstempo_convention))
+        self._prepared = False
+
+    def set_white_noise(self, efac=1.0, log10_equad=None, flagid="f", flags=None, tnequad=False):
+        """EFAC/EQUAD (white_noise.py:47-125).  Scalars, per-pulsar lists of scalars, or (with `flags`, a per-pulsar
+        list of flag lists) per-pulsar lists of per-flag arrays."""
+        self._wn = dict(efac=efac, log10_equad=log10_equad, flagid=flagid, flags=flags, tnequad=bool(tnequad))
+        self._prepared = False
+
+    def set_jitter(self, log10_ecorr, flagid="f", flags=None, coarsegrain=0.1):
+        """ECORR (white_noise.py:128-198)."""
+        self._ec = dict(log10_ecorr=log10_ecorr, flagid=flagid, flags=flags, coarsegrain=float(coarsegrain))
+        self._prepared = False
+
+    def set_gwb(self, log10_amplitude, spectral_index, no_correlations=False, turnover=False,
+                clm=(np.sqrt(4.0 * np.pi),), lmax=0, f0=1e-9, beta=1, power=1, userSpec=None, npts=600, howml=10):
+        """common GWB process (red_noise.py:138-298)."""
+        self._gw = dict(A=log10_amplitude, g=spectral_index, no_correlations=no_correlations, turnover=turnover, clm=clm,
+                        lmax=lmax, f0=f0, beta=beta, power=power, userSpec=userSpec, npts=npts, howml=howml)
+        self._prepared = False
+
+    def add_cgw(self, **kw):
+        """a continuous-wave source shared by all pulsars (deterministic.py:13-185); same keyword arguments."""
+        self._det = (self._det or []) + [kw]
+        self._prepared = False
+
+    # ---------------------------------------------------------------- helpers -------------------
+    def _flag_array(self, a, flagid):
+        return np.array([f[flagid] for f in self.psrs[a].toas.table["flags"].data])
+
+    # ---------------------------------------------------------------- prepare -------------------
+    def prepare(self):
+        dev = dv.require_gpu()
+        s = dv.stream_ptr()
+        P, N = self.P, self.n_toa
+        self.d_psr_of = dv.i32(np.repeat(np.arange(P), self.counts))
+        self.d_idx_in = dv.i32(np.concatenate([np.arange(c) for c in self.counts]))
+        self.d_toa_s = dv.f64(np.concatenate([m.astype(float) * 86400 for m in self.mjd]))
+        self.plan = _lib.EnginePlan()
+        pl = self.plan
+        pl.n_toa, pl.n_psr = N, P
+        pl.psr_of_toa, pl.idx_in_psr = self.d_psr_of.data_ptr(), self.d_idx_in.data_ptr()
+        pl.toa_s = self.d_toa_s.data_ptr()
+
+        # ---- red noise: Ft [K, N] over the concatenated TOAs and amp = sqrt(prior) [P, K]
+        pl.rn_k = 0
+        if self._rn is not None:
+            nm = self._rn["components"]
+            K = 2 * nm
+            self.K = K
+            self.d_Ft = dv.zeros((K, N))
+            amp = np.zeros((P, K))
+            self.rn_freqs = []
+            for a in range(P):
+                lA, g = self._rn["A"][a], self._rn["g"][a]
+                toas = self.tdb_s[a]
+                Tspan = toas.max() - toas.min()
+                f = 1.0 * np.arange(1, nm + 1) / Tspan
+                self.rn_freqs.append(f)
+                if lA is None or g is None:
+                    continue
+                freqs = np.repeat(f, 2)
+                fyr = 1 / YEAR_IN_SEC
+                prior = (10 ** lA) ** 2 * (freqs / fyr) ** (-g) / (12 * np.pi ** 2 * Tspan) * YEAR_IN_SEC ** 3
+                amp[a] = np.sqrt(prior)
+                t_d, f_d = dv.f64(toas), dv.f64(f)
+                lib_conv = self._rn["libstempo"]
+                t_ref = float(toas[0]) if lib_conv else 0.0
+                _lib.call("pta_rn_basis", dv.ptr(t_d), len(toas), ctypes.c_double(t_ref), dv.ptr(f_d), None, nm,
+                          1 if lib_conv else 0, ctypes.c_void_p(self.d_Ft.data_ptr() + 8 * int(self.off[a])), N, s)
+            torch.cuda.current_stream().synchronize()  # t_d/f_d temporaries die with the loop
+            self.rn_amp = amp
+            self.d_amp = dv.f64(amp)
+            pl.rn_k, pl.Ft, pl.ldf = K, self.d_Ft.data_ptr(), N
+
+        # ---- EFAC / EQUAD vectors
+        pl.wn_a = pl.wn_b = None
+        if self._wn is not None:
+            c = self._wn
+            wa, wb = np.zeros(N), np.zeros(N)
+            self.efacvec, self.equadvec = [], []
+            for a in range(P):
+                n = self.counts[a]
+                efac = self._pick(c["efac"], a)
+                l10 = self._pick(c["log10_equad"], a)
+                flags = self._pick_flags(c["flags"], a)
+                equad = 10 ** np.asarray(l10, dtype=float) if l10 is not None else 0.0
+                if flags is None:
+                    if not np.isscalar(efac) or np.ndim(equad) != 0:
+                        raise ValueError("ERROR: If flags is None, efac and equad must be a scalar")
+                    ev, qv = np.ones(n) * efac, np.ones(n) * float(equad)
+                else:
+                    ev, qv = np.zeros(n), np.zeros(n)
+                    if not (len(efac) == len(flags) and len(equad) == len(flags)):
+                        raise ValueError("ERROR: flags must be same length as efac and log10_equad")
+                    tf = self._flag_array(a, c["flagid"])
+                    for ct, flag in enumerate(flags):
+                        ev[flag == tf] = efac[ct]
+                        qv[flag == tf] = equad[ct]
+                self.efacvec.append(ev)
+                self.equadvec.append(qv)
+                sl = slice(self.off[a], self.off[a + 1])
+                wa[sl] = ev * self.sigma_s[a]
+                wb[sl] = qv if c["tnequad"] else ev * qv
+            self.d_wn_a, self.d_wn_b = dv.f64(wa), dv.f64(wb)
+            pl.wn_a, pl.wn_b, pl.tnequad = self.d_wn_a.data_ptr(), self.d_wn_b.data_ptr(), int(c["tnequad"])
+
+        # ---- ECORR epoch maps
+        pl.epoch_of = pl.ecorr_toa = None
+        if self._ec is not None:
+            c = self._ec
+            ep_all, ec_all = np.zeros(N, dtype=np.int32), np.zeros(N)
+            self.epoch_of, self.ecorrvec = [], []
+            for a in range(P):
+                l10 = self._pick(c["log10_ecorr"], a)
+                flags = self._pick_flags(c["flags"], a)
+                epoch_of, first = wn.epoch_map(self.mjd[a], c["coarsegrain"])
+                ne = len(first)
+                if l10 is None:
+                    vec = np.zeros(ne)
+                elif flags is None:
+                    if not np.isscalar(l10):
+                        raise ValueError("ERROR: If flags is None, jitter must be a scalar")
+                    vec = np.ones(ne) * 10 ** l10
+                else:
+                    ecorr = 10 ** np.asarray(l10, dtype=float)
+                    if len(ecorr) != len(flags):
+                        raise ValueError("ERROR: flags must be same length as jitter")
+                    aveflags = self._flag_array(a, c["flagid"])[first]
+                    vec = np.zeros(ne)
+                    for ct, flag in enumerate(flags):
+                        vec[flag == aveflags] = ecorr[ct]
+                self.epoch_of.append(epoch_of)
+                self.ecorrvec.append(vec)
+                sl = slice(self.off[a], self.off[a + 1])
+                ep_all[sl] = epoch_of
+                ec_all[sl] = vec[epoch_of]
+            self.d_epoch_of, self.d_ecorr_toa = dv.i32(ep_all), dv.f64(ec_all)
+            pl.epoch_of, pl.ecorr_toa = self.d_epoch_of.data_ptr(), self.d_ecorr_toa.data_ptr()
+
+        # ---- GWB: grid, ORF, Cholesky, spectrum, twiddles, brackets
+        pl.gw_npts = 0
+        if self._gw is not None:
+            c = self._gw
+            grid = rn.gwb_time_grid(self.psrs_ideal_view(), c["npts"], c["howml"])
+            self.grid = grid
+            npts, Nf = grid["npts"], grid["Nf"]
+            ORF = rn.gwb_orf_device(self.psrs, c["no_correlations"], c["clm"], c["lmax"])
+            self.ORF = ORF.clone()
+            self.d_M = rn.cholesky_device(ORF)
+            self.C = rn.gwb_spectrum(grid["f"], grid["dur"], c["howml"], c["A"], c["g"], c["turnover"], c["f0"], c["beta"],
+                                     c["power"], c["userSpec"])
+            self.ldt = rn.pad16(npts)
+            self.d_T = dv.empty((2 * (Nf - 2), self.ldt))
+            sqrtC = dv.f64(self.C ** 0.5)
+            _lib.call("pta_gwb_twiddle", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_T), self.ldt, s)
+            self.d_ut = dv.f64(grid["ut"])
+            self.d_jlo = dv.empty((N,), dtype=torch.int32)
+            _lib.call("pta_gwb_bracket", dv.ptr(self.d_ut), npts, dv.ptr(self.d_toa_s), N, dv.ptr(self.d_jlo), s)
+            torch.cuda.current_stream().synchronize()
+            pl.gw_npts, pl.gw_ut, pl.gw_jlo = npts, self.d_ut.data_ptr(), self.d_jlo.data_ptr()
+
+        # ---- deterministic signals (CGW), summed once
+        pl.det = None
+        if self._det:
+            self.d_det = dv.zeros((N,))
+            for kw in self._det:
+                for a in range(P):
+                    ra, dec = ra_dec(self.psrs[a])
+                    par, _, _, _ = det.cgw_parameters(np.pi / 2 - dec, ra, **{k: v for k, v in kw.items() if k != "signal_name"})
+                    mjd_d = dv.f64(self.mjd[a])
+                    par = np.ascontiguousarray(par)
+                    _lib.call("pta_cgw", dv.ptr(mjd_d), len(self.mjd[a]), dv.hptr(par),
+                              ctypes.c_void_p(self.d_det.data_ptr() + 8 * int(self.off[a])), 1, s)
+                    torch.cuda.current_stream().synchronize()
+            pl.det = self.d_det.data_ptr()
+        self._prepared = True
+        return self
+
+    def psrs_ideal_view(self):
+        """objects exposing first_MJD/last_MJD of the IDEAL TOAs for the GWB grid (red_noise.py:182-183)."""
+        class _V:
+            pass
+        out = []
+        for m in self.mjd:
+            v = _V()
+            v.toas = _V()
+            v.toas.first_MJD = _V()
+            v.toas.last_MJD = _V()
+            v.toas.first_MJD.value = float(m.min())
+            v.toas.last_MJD.value = float(m.max())
+            out.append(v)
+        return out
+
+    def _pick(self, val, a):
+        """per-pulsar entry of a scalar / list-of-P parameter."""
+        if val is None or np.isscalar(val):
+            return val
+        if len(val) != self.P:
+            raise ValueError(f"expected a scalar or one entry per pulsar ({self.P}), got {len(val)}")
+        return val[a]
+
+    def _pick_flags(self, flags, a):
+        if flags is None:
+            return None
+        if len(flags) != self.P:
+            raise ValueError("flags must be a per-pulsar list of flag lists")
+        return flags[a]
+
+    # ---------------------------------------------------------------- throughput mode -----------
+    def workspace(self, R):
+        """device buffers for a batch of R realisations (reused across generate() calls)."""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws["R"] < R:
+            ws = {"R": R}
+            if self.plan.rn_k:
+                ws["coef"] = dv.empty((R, self.P, self.K))
+            if self.plan.gw_npts:
+                ws["G0"] = dv.empty((R, self.P, self.plan.gw_npts))
+                ws["G"] = dv.empty((R, self.P, self.plan.gw_npts))
+            self._ws = ws
+        return ws
+
+    def generate(self, R, r0=0, out=None):
+        """out[R, n_toa] (device tensor, seconds): realisations r0 .. r0+R-1, every deviate drawn on chip."""
+        if not self._prepared:
+            self.prepare()
+        s = dv.stream_ptr()
+        if out is None:
+            out = dv.empty((R, self.n_toa))
+        ws = self.workspace(R)
+        pl = self.plan
+        if pl.rn_k:
+            _lib.call("pta_engine_rn_coef", self.seed, r0, R, self.P, self.K, dv.ptr(self.d_amp), dv.ptr(ws["coef"]), s)
+            pl.rn_coef = ws["coef"].data_ptr()
+        if pl.gw_npts:
+            npts = pl.gw_npts
+            _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_T), self.ldt, npts,
+                      dv.ptr(ws["G0"]), npts, s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), self.P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s)
+            pl.gw_G = ws["G"].data_ptr()
+        _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(out), out.stride(0), s)
+        return out
+
+    # ---------------------------------------------------------------- replay mode ---------------
+    def dump_draws(self, r):
+        """The normals realisation r uses in generate(), as NumPy arrays in the reference's shapes:
+        {'gwb': w[P,Nf] complex, 'rn': [z[K]], 'wn': [(z1[N_a], z2[N_a])], 'ecorr': [z[E_a]]}."""
+        if not self._prepared:
+            self.prepare()
+        s = dv.stream_ptr()
+        d = {}
+        if self.plan.gw_npts:
+            Nf = self.grid["Nf"]
+            buf = dv.empty((self.P, 2 * Nf))
+            for a in range(self.P):
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_GWB, a), Nf, 1,
+                          ctypes.c_void_p(buf.data_ptr() + 16 * Nf * a), None, 2 * Nf, s)
+            w = buf.cpu().numpy().reshape(self.P, Nf, 2)
+            d["gwb"] = w[:, :, 0] + 1j * w[:, :, 1]
+        if self.plan.rn_k:
+            d["rn"] = []
+            for a in range(self.P):
+                buf = dv.empty((self.K,))
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_RN, a), self.K // 2, 1, dv.ptr(buf), None, self.K, s)
+                d["rn"].append(buf.cpu().numpy())
+        if self.plan.wn_a:
+            d["wn"] = []
+            for a in range(self.P):
+                n = int(self.counts[a])
+                z1, z2 = dv.empty((n,)), dv.empty((n,))
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_WN, a), n, 0, dv.ptr(z1), dv.ptr(z2), n, s)
+                d["wn"].append((z1.cpu().numpy(), z2.cpu().numpy()))
+        if self.plan.ecorr_toa:
+            d["ecorr"] = []
+            for a in range(self.P):
+                ne = len(self.ecorrvec[a])
+                npair = (ne + 1) // 2
+                buf = dv.empty((2 * npair,))
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_ECORR, a), npair, 1, dv.ptr(buf), None, 2 * npair, s)
+                d["ecorr"].append(buf.cpu().numpy()[:ne])
+        return d
+
+    def replay(self, draws_list, per_signal=False):
+        """Push caller-supplied draws through the per-signal kernels (replay mode / parity path).
+
+        draws_list: one dict per realisation, shaped like dump_draws().  Returns out[R, n_toa] (device), or with
+        per_signal=True a dict of such tensors keyed 'rn', 'gwb', 'wn', 'ecorr', 'det', 'total'."""
+        if not self._prepared:
+            self.prepare()
+        s = dv.stream_ptr()
+        R, P, N = len(draws_list), self.P, self.n_toa
+        sig = {}
+        pl = self.plan
+        if pl.rn_k:
+            coef = np.zeros((R, P, self.K))
+            for r, d in enumerate(draws_list):
+                for a in range(P):
+                    coef[r, a] = self.rn_amp[a] * d["rn"][a]
+            coef_d = dv.f64(coef)
+            out = dv.zeros((R, N))
+            for a in range(P):
+                n = int(self.counts[a])
+                _lib.call("pta_rn_synth", ctypes.c_void_p(self.d_Ft.data_ptr() + 8 * int(self.off[a])), N, n, self.K,
+                          ctypes.c_void_p(coef_d.data_ptr() + 8 * a * self.K), P * self.K, R,
+                          ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, s)
+            sig["rn"] = out
+        if pl.gw_npts:
+            Nf, npts = self.grid["Nf"], pl.gw_npts
+            w = np.zeros((R, P, Nf, 2))
+            for r, d in enumerate(draws_list):
+                w[r, :, :, 0], w[r, :, :, 1] = d["gwb"].real, d["gwb"].imag
+            w_d = dv.f64(w)
+            G0, G = dv.empty((R * P, npts)), dv.empty((R * P, npts))
+            _lib.call("pta_gwb_idft", dv.ptr(w_d), 2 * Nf, R * P, Nf, dv.ptr(self.d_T), self.ldt, npts, dv.ptr(G0), npts, 1, s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), s)
+            out = dv.empty((R, N))
+            _lib.call("pta_gwb_interp", dv.ptr(G), npts, P, npts, dv.ptr(self.d_ut), dv.ptr(self.d_toa_s), dv.ptr(self.d_psr_of),
+                      dv.ptr(self.d_jlo), N, R, ctypes.c_double(1.0), dv.ptr(out), N, 0, s)
+            sig["gwb"] = out
+            self._last_G = G
+        if pl.wn_a:
+            z1 = np.zeros((R, N)); z2 = np.zeros((R, N))
+            for r, d in enumerate(draws_list):
+                z1[r] = np.concatenate([x[0] for x in d["wn"]]); z2[r] = np.concatenate([x[1] for x in d["wn"]])
+            sg, ef, eq = dv.f64(np.concatenate(self.sigma_s)), dv.f64(np.concatenate(self.efacvec)), dv.f64(np.concatenate(self.equadvec))
+            z1_d, z2_d = dv.f64(z1), dv.f64(z2)
+            out = dv.empty((R, N))
+            _lib.call("pta_wn", dv.ptr(sg), dv.ptr(ef), dv.ptr(eq), N, int(self._wn["tnequad"]), dv.ptr(z1_d), dv.ptr(z2_d), N, R,
+                      dv.ptr(out), N, 0, s)
+            sig["wn"] = out
+        if pl.ecorr_toa:
+            out = dv.zeros((R, N))
+            for a in range(P):
+                ne, n = len(self.ecorrvec[a]), int(self.counts[a])
+                z = np.zeros((R, ne))
+                for r, d in enumerate(draws_list):
+                    z[r] = d["ecorr"][a]
+                z_d, ep_d, ec_d = dv.f64(z), dv.i32(self.epoch_of[a]), dv.f64(self.ecorrvec[a])
+                _lib.call("pta_ecorr", dv.ptr(ep_d), dv.ptr(ec_d), n, ne, dv.ptr(z_d), ne, R,
+                          ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, s)
+                torch.cuda.current_stream().synchronize()
+            sig["ecorr"] = out
+        total = dv.zeros((R, N))
+        for k in ("rn", "gwb", "wn", "ecorr"):
+            if k in sig:
+                total += sig[k]
+        if pl.det:
+            sig["det"] = self.d_det.unsqueeze(0).expand(R, N)
+            total += self.d_det
+        torch.cuda.current_stream().synchronize()
+        if per_signal:
+            sig["total"] = total
+            return sig
+        return total
+
+    def split(self, arr):
+        """per-pulsar views of an [..., n_toa] array."""
+        return [arr[..., self.off[a]:self.off[a + 1]] for a in range(self.P)]

@@ -1,0 +1,300 @@
+"""Pulsar container and loaders: the drop-in boundary of the injection functions.
+
+Mirrors ``pta_replicator/simulate.py`` (SimulatedPulsar :23-95, simulate_pulsar :98-135, load_pulsar
+:138-167, load_from_directories :170-190, make_ideal :193-202).  This is host-side bookkeeping and is
+deliberately NOT accelerated (BASELINE.json: "Python host code owns the Pulsar/TOA bookkeeping").
+
+Two kinds of pulsar work with every ``add_*`` function of this package:
+
+* PINT-backed: any object with the reference's duck-type surface - e.g. the reference's
+  own ``SimulatedPulsar`` holding ``pint.toa.TOAs`` + ``TimingModel``.  Used as is when PINT is installed.
+* array-backed: ``ArrayTOAs`` below keeps the TOAs as a longdouble MJD column (the precision of PINT's
+  ``tdbld``), implements the same surface, and defines the residual as PINT does for an idealised
+  pulsar: accumulated TOA shift minus the weighted mean.  This is what runs on machines without
+  PINT/astropy (the GPU box) and what the batched engine is built from.
+"""
+import glob
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._compat import HAVE_ASTROPY, TimeDelta, delta_days, u  # noqa: F401
+
+try:  # pragma: no cover - depends on the environment
+    import pint.toa as _pint_toa
+    from pint import models as _pint_models
+    from pint.residuals import Residuals as _PintResiduals
+    from pint.simulation import make_fake_toas_fromMJDs as _make_fake_toas_fromMJDs
+    import pint.fitter as _pint_fitter
+    HAVE_PINT = True
+except ImportError:
+    HAVE_PINT = False
+
+
+class _Column:
+    def __init__(self, data):
+        self.data = data
+
+
+class _Scalar:
+    def __init__(self, value):
+        self.value = value
+
+
+class ArrayResiduals:
+    """time residuals of an idealised pulsar: total injected delay, weighted-mean subtracted (PINT's default)."""
+
+    def __init__(self, toas):
+        # the accumulated shift is tracked on its own: differencing two longdouble MJDs (resolution 2.5e-10 s at
+        # MJD 53000) would bury the 1e-10-relative parity this package is tested to
+        shift = (toas.shift_day_ld * np.longdouble(86400)).astype(np.float64)
+        w = 1.0 / toas.errors_us ** 2
+        self.resids_value = shift - np.sum(shift * w) / np.sum(w)
+        self._err_us = toas.errors_us
+
+    @property
+    def time_resids(self):
+        return self.resids_value * u.s
+
+    def get_data_error(self):
+        return self._err_us * u.us
+
+
+class ArrayTOAs:
+    """TOA table with the surface the injection functions touch, in longdouble MJD."""
+
+    def __init__(self, mjd, errors_us, flags=None, freqs_mhz=1440.0):
+        self.mjd0_ld = np.array(mjd, dtype=np.longdouble)  # "ideal" TOAs: zero residual by construction
+        self.mjd_ld = self.mjd0_ld.copy()
+        self.shift_day_ld = np.zeros(len(self.mjd_ld), dtype=np.longdouble)  # sum of all adjust_TOAs() deltas
+        n = len(self.mjd_ld)
+        self.errors_us = np.asarray(errors_us, dtype=np.float64) * np.ones(n)
+        self.freqs_mhz = np.asarray(freqs_mhz, dtype=np.float64) * np.ones(n)
+        self.flags = list(flags) if flags is not None else [dict() for _ in range(n)]
+        if len(self.flags) != n or len(self.errors_us) != n:
+            raise ValueError("mjd, errors and flags must have the same length")
+
+    @property
+    def table(self):
+        return {"tdbld": self.mjd_ld, "flags": _Column(self.flags)}
+
+    @property
+    def ntoas(self):
+        return len(self.mjd_ld)
+
+    def get_mjds(self):
+        return self.mjd_ld.astype(np.float64) * u.day
+
+    @property
+    def first_MJD(self):
+        return _Scalar(float(self.mjd_ld.min()))
+
+    @property
+    def last_MJD(self):
+        return _Scalar(float(self.mjd_ld.max()))
+
+    def get_errors(self):
+        return self.errors_us.copy() * u.us
+
+    def adjust_TOAs(self, delta):
+        d = delta_days(delta).astype(np.longdouble)
+        self.mjd_ld = self.mjd_ld + d
+        self.shift_day_ld = self.shift_day_ld + d
+
+    def reset_ideal(self):
+        self.mjd_ld = self.mjd0_ld.copy()
+        self.shift_day_ld = np.zeros(len(self.mjd_ld), dtype=np.longdouble)
+
+
+@dataclass
+class SimulatedPulsar:
+    """Same fields and methods as the reference's dataclass (simulate.py:23-95)."""
+    ephem: str = "DE440"
+    model: object = None
+    toas: object = None
+    residuals: object = None
+    name: str = None
+    loc: dict = None
+    added_signals: dict = None
+    added_signals_time: dict = None
+
+    def __repr__(self):
+        return f"SimulatedPulsar({self.name})"
+
+    def update_residuals(self):
+        """Rebuild the residuals from the current TOAs (simulate.py:40-42)."""
+        if isinstance(self.toas, ArrayTOAs):
+            self.residuals = ArrayResiduals(self.toas)
+        else:
+            self.residuals = _PintResiduals(self.toas, self.model)
+
+    def fit(self, fitter="auto", **fitter_kwargs):
+        """Refit the timing model (simulate.py:44-69); needs PINT."""
+        if isinstance(self.toas, ArrayTOAs) or not HAVE_PINT:
+            raise NotImplementedError("fit() needs a PINT-backed pulsar (pint-pulsar is not installed here)")
+        if fitter == "wls":
+            self.f = _pint_fitter.WLSFitter(self.toas, self.model)
+        elif fitter == "gls":
+            self.f = _pint_fitter.GLSFitter(self.toas, self.model)
+        elif fitter == "downhill":
+            self.f = _pint_fitter.DownhillGLSFitter(self.toas, self.model)
+        elif fitter == "auto":
+            self.f = _pint_fitter.Fitter.auto(self.toas, self.model)
+        else:
+            raise ValueError(f"{fitter=} must be one of 'wls', 'gls', 'downhill' or 'auto'")
+        self.f.fit_toas(**fitter_kwargs)
+        self.model = self.f.model
+        self.update_residuals()
+
+    def write_partim(self, outpar, outtim, tempo2=False):
+        """Write par/tim (simulate.py:71-77).  Array-backed pulsars write a Tempo2 tim file only."""
+        if isinstance(self.toas, ArrayTOAs):
+            with open(outtim, "w") as fh:
+                fh.write("FORMAT 1\n")
+                for i in range(self.toas.ntoas):
+                    fl = " ".join(f"-{k} {v}" for k, v in self.toas.flags[i].items())
+                    fh.write(f" {self.name} {self.toas.freqs_mhz[i]:.8f} {np.format_float_positional(self.toas.mjd_ld[i], precision=19)} "
+                             f"{self.toas.errors_us[i]:.5f} AXIS {fl}\n")
+            return
+        self.model.write_parfile(outpar)
+        self.toas.write_TOA_file(outtim, format="Tempo2") if tempo2 else self.toas.write_TOA_file(outtim)
+
+    def update_added_signals(self, signal_name, param_dict, dt=None):
+        """Record an injected signal; same checks and messages as simulate.py:79-89."""
+        if self.added_signals is None:
+            raise ValueError("make_ideal() must be called on SimulatedPulsar before adding new signals.")
+        if signal_name in self.added_signals:
+            raise ValueError(f"{signal_name} already exists in the model.")
+        self.added_signals[signal_name] = param_dict
+        if dt is not None:
+            self.added_signals_time[signal_name] = dt
+
+    def to_enterprise(self, ephem="DE440"):
+        """enterprise PintPulsar (simulate.py:91-95); needs enterprise + PINT."""
+        from enterprise.pulsar import Pulsar
+        return Pulsar(self.toas, self.model, ephem=ephem, timing_package="pint")
+
+
+# ----------------------------------------------------------------------------------------------
+# par / tim readers for the array-backed path
+# ----------------------------------------------------------------------------------------------
+def _sexagesimal(text):
+    text = text.strip()
+    sign = -1.0 if text.startswith("-") else 1.0
+    parts = [np.longdouble(p) for p in text.lstrip("+-").split(":")]
+    parts += [np.longdouble(0)] * (3 - len(parts))
+    return float(sign * (parts[0] + parts[1] / 60 + parts[2] / 3600))
+
+
+def read_par_location(parfile):
+    """(name, loc): loc = {'RAJ' [hourangle], 'DECJ' [deg]} or {'ELONG','ELAT'} [deg], as simulate.py:127-132."""
+    if not os.path.isfile(parfile):
+        raise FileNotFoundError("par file does not exist.")
+    vals = {}
+    with open(parfile) as fh:
+        for line in fh:
+            tok = line.split()
+            if len(tok) >= 2 and tok[0] in ("PSR", "PSRJ", "PSRB", "RAJ", "DECJ", "ELONG", "ELAT", "LAMBDA", "BETA"):
+                vals.setdefault(tok[0], tok[1])
+    name = vals.get("PSR", vals.get("PSRJ", vals.get("PSRB")))
+    if "RAJ" in vals and "DECJ" in vals:
+        loc = {"RAJ": _sexagesimal(vals["RAJ"]), "DECJ": _sexagesimal(vals["DECJ"])}
+    elif ("ELONG" in vals or "LAMBDA" in vals) and ("ELAT" in vals or "BETA" in vals):
+        loc = {"ELONG": float(vals.get("ELONG", vals.get("LAMBDA"))), "ELAT": float(vals.get("ELAT", vals.get("BETA")))}
+    else:
+        raise AttributeError("No pulsar location information (RAJ/DECJ or ELONG/ELAT) in parfile.")
+    return name, loc
+
+
+def read_tim(timfile):
+    """Tempo2-format tim file -> (mjd longdouble[N], error_us[N], freq_mhz[N], flags list[dict])."""
+    if not os.path.isfile(timfile):
+        raise FileNotFoundError("tim file does not exist.")
+    mjd, err, freq, flags = [], [], [], []
+    with open(timfile) as fh:
+        for line in fh:
+            tok = line.split()
+            if len(tok) < 5 or tok[0] in ("FORMAT", "MODE", "C", "#", "JUMP", "SKIP", "NOSKIP", "TIME", "INCLUDE", "EFAC", "EQUAD"):
+                continue
+            try:
+                f_, m_, e_ = float(tok[1]), np.longdouble(tok[2]), float(tok[3])
+            except ValueError:
+                continue
+            fl, rest, i = {}, tok[5:], 0
+            while i + 1 < len(rest):
+                key = rest[i]
+                is_num = key.lstrip("-").replace(".", "", 1).replace("e", "", 1).isdigit()
+                if key.startswith("-") and not is_num:
+                    fl[key[1:]] = rest[i + 1]
+                    i += 2
+                else:
+                    i += 1
+            mjd.append(m_); err.append(e_); freq.append(f_); flags.append(fl)
+    return np.array(mjd, dtype=np.longdouble), np.array(err), np.array(freq), flags
+
+
+def simulate_pulsar(parfile, obstimes, toaerr, freq=1440.0, observatory="AXIS", flags=None, ephem="DE440"):
+    """SimulatedPulsar from a par file and observation times [MJD] (simulate.py:98-135)."""
+    if not os.path.isfile(parfile):
+        raise FileNotFoundError("par file does not exist.")
+    if HAVE_PINT:  # pragma: no cover
+        model = _pint_models.get_model(parfile)
+        toas = _make_fake_toas_fromMJDs(obstimes, model, freq=freq * u.MHz, obs=observatory, flags=flags, error=toaerr * u.us)
+        name, loc = read_par_location(parfile)
+        return SimulatedPulsar(ephem=ephem, model=model, toas=toas, residuals=_PintResiduals(toas, model), name=model.PSR.value, loc=loc)
+    name, loc = read_par_location(parfile)
+    n = len(obstimes)
+    fl = [dict(flags) for _ in range(n)] if isinstance(flags, dict) else flags
+    toas = ArrayTOAs(obstimes, toaerr, fl, freq)
+    psr = SimulatedPulsar(ephem=ephem, model=None, toas=toas, name=name, loc=loc)
+    psr.update_residuals()
+    return psr
+
+
+def load_pulsar(parfile, timfile, ephem="DE440"):
+    """SimulatedPulsar from par + tim files (simulate.py:138-167)."""
+    if not os.path.isfile(parfile):
+        raise FileNotFoundError("par file does not exist.")
+    if not os.path.isfile(timfile):
+        raise FileNotFoundError("tim file does not exist.")
+    name, loc = read_par_location(parfile)
+    if HAVE_PINT:  # pragma: no cover
+        model = _pint_models.get_model(parfile)
+        toas = _pint_toa.get_TOAs(timfile, ephem=ephem, planets=True)
+        return SimulatedPulsar(ephem=ephem, model=model, toas=toas, residuals=_PintResiduals(toas, model), name=model.PSR.value, loc=loc)
+    mjd, err, freq, flags = read_tim(timfile)
+    psr = SimulatedPulsar(ephem=ephem, model=None, toas=ArrayTOAs(mjd, err, flags, freq), name=name, loc=loc)
+    psr.update_residuals()
+    return psr
+
+
+def load_from_directories(pardir, timdir, ephem="DE440", num_psrs=None, debug=False):
+    """Pair sorted par and tim files of two directories (simulate.py:170-190)."""
+    if not os.path.isdir(pardir):
+        raise FileNotFoundError("par directory does not exist.")
+    if not os.path.isdir(timdir):
+        raise FileNotFoundError("tim directory does not exist.")
+    pars = [p for p in sorted(glob.glob(pardir + "/*.par")) if ".t2" not in p]
+    tims = sorted(glob.glob(timdir + "/*.tim"))
+    psrs = []
+    for par, tim in zip(pars, tims):
+        if num_psrs and len(psrs) >= num_psrs:
+            break
+        if debug:
+            print(f"loading {par=}, {tim=}")
+        psrs.append(load_pulsar(par, tim, ephem=ephem))
+    return psrs
+
+
+def make_ideal(psr, iterations=2):
+    """Zero the residuals and open the added-signal registry (simulate.py:193-202)."""
+    if isinstance(psr.toas, ArrayTOAs):
+        psr.toas.reset_ideal()  # array-backed TOAs carry their ideal column: exact in one step
+    else:  # pragma: no cover - PINT path, same iteration as the reference
+        for _ in range(iterations):
+            residuals = _PintResiduals(psr.toas, psr.model)
+            psr.toas.adjust_TOAs(TimeDelta(-1.0 * residuals.time_resids))
+    psr.added_signals = {}
+    psr.added_signals_time = {}
+    psr.update_residuals()

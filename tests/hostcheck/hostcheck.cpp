@@ -1,0 +1,44 @@
+// TEST HARNESS (not product code): compiles the __host__ __device__ math headers of
+// pta_replicator_amd/csrc with g++ so that the exact device formulas can be checked against the
+// oracle / golden vectors on a machine without a GPU.  Loaded by tests/test_hostcheck.py via ctypes.
+#include <stdint.h>
+#include "../../pta_replicator_amd/csrc/pta_rng.h"
+#include "../../pta_replicator_amd/csrc/pta_orf.h"
+
+extern "C" {
+
+void hc_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+  pta_u32x4 c = {ctr[0], ctr[1], ctr[2], ctr[3]};
+  pta_u32x4 v = pta_philox4x32_10(c, key[0], key[1]);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
+void hc_normal_pairs(uint64_t seed, uint64_t realisation, uint32_t stream, int npairs, double *out) {
+  for (int p = 0; p < npairs; ++p) pta_normal_pair(seed, realisation, stream, (uint32_t)p, out[2 * p], out[2 * p + 1]);
+}
+
+void hc_uniform_pairs(uint64_t seed, uint64_t realisation, uint32_t stream, int npairs, double *out) {
+  for (int p = 0; p < npairs; ++p) pta_uniform_pair(pta_philox_draw(seed, realisation, stream, (uint32_t)p), out[2 * p], out[2 * p + 1]);
+}
+
+uint32_t hc_stream_id(uint32_t kind, uint32_t pulsar) { return pta_stream_id(kind, pulsar); }
+
+void hc_orf_hd(const double *locs, int P, double *orf) {
+  for (int a = 0; a < P; ++a)
+    for (int b = 0; b < P; ++b) orf[a * P + b] = pta_orf_hd(locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1]);
+}
+
+void hc_orf_basis(const double *locs, int P, int lmax, double *basis) {
+  for (int l = 0; l <= lmax; ++l)
+    for (int a = 0; a < P; ++a)
+      for (int b = a; b < P; ++b) {
+        double v[2 * PTA_ORF_LMAX + 1];
+        pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], v);
+        for (int mi = 0; mi <= 2 * l; ++mi) {
+          int k = l * l + mi;
+          basis[((int64_t)k * P + a) * P + b] = v[mi];
+          basis[((int64_t)k * P + b) * P + a] = v[mi];
+        }
+      }
+}
+}

@@ -1,0 +1,222 @@
+"""GPU tests of the C-ABI building blocks (run with -m gpu on an MI355X).
+
+Every test calls the HIP library through the ctypes boundary and compares with NumPy / the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import load
+from oracle import philox_ref
+from oracle import pta_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    from pta_replicator_amd import _lib, device as dv
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return dict(torch=torch, lib=_lib, dv=dv, s=dv.stream_ptr())
+
+
+def test_device_and_mfma_layout(gpu):
+    info = gpu["dv"].device_info()
+    assert info["wavefront"] == 64 and info["arch"].startswith("gfx950"), info
+    err = ctypes.c_double(-1.0)
+    gpu["lib"].call("pta_selftest_mfma_f64", ctypes.byref(err))
+    assert err.value < 1e-12
+
+
+def test_philox_known_answers_on_device(gpu):
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, expect in kat:
+        c = torch.tensor(np.array(ctr, dtype=np.uint32).view(np.int32), device="cuda")
+        k = torch.tensor(np.array(key, dtype=np.uint32).view(np.int32), device="cuda")
+        o = torch.zeros(4, dtype=torch.int32, device="cuda")
+        lib.call("pta_rng_philox_raw", dv.ptr(c), dv.ptr(k), 1, dv.ptr(o), gpu["s"])
+        assert [int(x) for x in o.cpu().numpy().view(np.uint32)] == expect
+
+
+@pytest.mark.parametrize("interleave", [0, 1])
+def test_rng_fill_matches_numpy_twin(gpu, interleave):
+    dv, lib = gpu["dv"], gpu["lib"]
+    seed, r0, R, npairs = 0xDEADBEEF12345678, (1 << 33) + 5, 3, 1000
+    sid = philox_ref.stream_id(philox_ref.STREAM_WN, 17)
+    if interleave:
+        z0 = dv.empty((R, 2 * npairs)); z1 = None
+        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 1, dv.ptr(z0), None, 2 * npairs, gpu["s"])
+        got0, got1 = z0.cpu().numpy()[:, 0::2], z0.cpu().numpy()[:, 1::2]
+    else:
+        z0, z1 = dv.empty((R, npairs)), dv.empty((R, npairs))
+        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 0, dv.ptr(z0), dv.ptr(z1), npairs, gpu["s"])
+        got0, got1 = z0.cpu().numpy(), z1.cpu().numpy()
+    for r in range(R):
+        e0, e1 = philox_ref.normal_pairs(seed, r0 + r, sid, npairs)
+        assert np.max(np.abs(got0[r] - e0)) < 1e-13 and np.max(np.abs(got1[r] - e1)) < 1e-13
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (70, 130, 37), (200, 600, 301), (3, 600, 2998)])
+@pytest.mark.parametrize("transB", [0, 1])
+def test_dgemm_mfma_and_valu(gpu, shape, transB):
+    dv, lib = gpu["dv"], gpu["lib"]
+    M, N, K = shape
+    rng = np.random.default_rng(M * 1000 + N + K)
+    A = rng.standard_normal((M, K)); B = rng.standard_normal((N, K) if transB else (K, N)); C0 = rng.standard_normal((M, N))
+    ref = 0.7 * A @ (B.T if transB else B) - 1.3 * C0
+    for algo in (0, 1):
+        Ad, Bd, Cd = dv.f64(A), dv.f64(B), dv.f64(C0)
+        lib.call("pta_dgemm", transB, M, N, K, 0.7, dv.ptr(Ad), K, 1, dv.ptr(Bd), B.shape[1], -1.3, dv.ptr(Cd), N, 0, 1, 0, 0, 0,
+                 algo, gpu["s"])
+        assert np.max(np.abs(Cd.cpu().numpy() - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (algo, shape)
+
+
+def test_dgemm_batched_strided_lower(gpu):
+    """batch + element stride on A (planes of interleaved complex) + SYRK-style lower_only."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    rng = np.random.default_rng(9)
+    Bt, M, K = 3, 97, 50
+    W = rng.standard_normal((Bt, M, K, 2))
+    C0 = rng.standard_normal((Bt, M, M))
+    for algo in (0, 1):
+        Wd, Cd = dv.f64(W), dv.f64(C0)
+        # C -= Re(W) Re(W)^T on the lower triangle
+        lib.call("pta_dgemm", 1, M, M, K, -1.0, dv.ptr(Wd), 2 * K, 2, dv.ptr(dv.f64(W[..., 0])), K, 1.0, dv.ptr(Cd), M, 1, Bt,
+                 M * K * 2, M * K, M * M, algo, gpu["s"])
+        got = Cd.cpu().numpy()
+        for b in range(Bt):
+            ref = C0[b] - W[b, :, :, 0] @ W[b, :, :, 0].T
+            lo = np.tril_indices(M)
+            up = np.triu_indices(M, 1)
+            assert np.max(np.abs(got[b][lo] - ref[lo])) < 1e-11
+            assert np.array_equal(got[b][up], C0[b][up])
+
+
+def test_orf_kernels_vs_reference_golden(gpu):
+    from pta_replicator_amd import spharmORFbasis as anis
+    z = load("orf_basis.npz")
+    locs, lmax, ref = z["psr_locs"], int(z["lmax"]), z["basis"]
+    basis = np.array(anis.correlated_basis(locs, lmax))
+    scale = np.max(np.abs(ref), axis=(1, 2), keepdims=True)
+    err = np.abs(basis - ref) / scale
+    # l <= 2 is well conditioned; l >= 3 cancels catastrophically near zeta -> 0, pi inside the reference itself
+    # (its own values move by 1e-10 under a 1-ulp change of pow()), hence the looser bar there
+    assert err[:9].max() < 1e-13 and err[9:].max() < 1e-9, (err[:9].max(), err[9:].max())
+    orf = anis.orf_from_locations(locs).cpu().numpy()
+    assert np.max(np.abs(orf - 2 * np.sqrt(4 * np.pi) * ref[0])) < 1e-14
+    clm = np.array([np.sqrt(4 * np.pi), 0.3, -0.2, 0.25])
+    orf2 = anis.orf_from_locations(locs, clm, 1).cpu().numpy()
+    assert np.max(np.abs(orf2 - 2 * sum(clm[k] * ref[k] for k in range(4)))) < 1e-13
+
+
+@pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (64, 1), (68, 1), (130, 4), (200, 2), (515, 1)])
+def test_potrf_batched_vs_numpy(gpu, n, batch):
+    from pta_replicator_amd import red_noise as rn
+    dv, lib = gpu["dv"], gpu["lib"]
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((batch, n, n + 5))
+    A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
+    for algo in (0, 1):
+        lib.call("pta_set_gemm_algo", algo)
+        L = rn.cholesky_device(dv.f64(A)).cpu().numpy()
+        ref = np.linalg.cholesky(A)
+        assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, algo)
+        assert np.all(np.triu(L, 1) == 0)
+    lib.call("pta_set_gemm_algo", 1)
+
+
+def test_potrf_not_positive_definite_raises(gpu):
+    from pta_replicator_amd import red_noise as rn
+    dv = gpu["dv"]
+    A = np.eye(70); A[66, 66] = -1.0
+    with pytest.raises(np.linalg.LinAlgError):
+        rn.cholesky_device(dv.f64(A))
+
+
+def test_potrf_headline_orf(gpu):
+    """68-pulsar Hellings-Downs ORF (config 3 geometry): device Cholesky vs LAPACK."""
+    from pta_replicator_amd import red_noise as rn, spharmORFbasis as anis
+    rng = np.random.default_rng(68)
+    locs = np.stack([rng.uniform(0, 24, 68) * np.pi / 12, np.pi / 2 - np.arcsin(rng.uniform(-1, 1, 68))], axis=1)
+    orf = anis.orf_from_locations(locs)
+    ref = np.linalg.cholesky(po.hd_orf_closed_form(locs))
+    M = rn.cholesky_device(orf).cpu().numpy()
+    assert np.max(np.abs(M - ref)) < 1e-13
+
+
+def test_gwb_idft_mfma_vs_fft(gpu):
+    """pruned inverse DFT as a GEMM == numpy's Hermitian-packed ifft, cropped (red_noise.py:275-285)."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    rng = np.random.default_rng(3)
+    for Nf, npts in ((3000, 600), (3001, 600), (601, 200)):
+        M = 5
+        w = rng.standard_normal((M, Nf, 2))
+        C = rng.uniform(0.5, 2.0, Nf) * 1e-14
+        dt = 1234.5
+        T = dv.empty((2 * (Nf - 2), 608))
+        lib.call("pta_gwb_twiddle", dv.ptr(dv.f64(C ** 0.5)), Nf, npts, 10, 1.0 / dt, dv.ptr(T), 608, gpu["s"])
+        Res_f = (w[..., 0] + 1j * w[..., 1]) * C ** 0.5
+        Res_f[:, 0] = 0; Res_f[:, -1] = 0
+        ref = po.gwb_time_series(Res_f, dt)[:, 10:npts + 10]
+        for algo in (0, 1):
+            G0 = dv.zeros((M, npts))
+            lib.call("pta_gwb_idft", dv.ptr(dv.f64(w)), 2 * Nf, M, Nf, dv.ptr(T), 608, npts, dv.ptr(G0), npts, algo, gpu["s"])
+            assert np.max(np.abs(G0.cpu().numpy() - ref)) < 1e-12 * np.max(np.abs(ref)), (Nf, algo)
+
+
+def test_gwb_idft_rng_equals_replay_of_its_draws(gpu):
+    dv, lib = gpu["dv"], gpu["lib"]
+    seed, r0, R, P, Nf, npts = 77, 1000, 3, 5, 3000, 600
+    C = np.linspace(2.0, 0.5, Nf) * 1e-14
+    T = dv.empty((2 * (Nf - 2), 608))
+    lib.call("pta_gwb_twiddle", dv.ptr(dv.f64(C ** 0.5)), Nf, npts, 10, 1.0 / 777.0, dv.ptr(T), 608, gpu["s"])
+    G_rng = dv.zeros((R * P, npts))
+    lib.call("pta_gwb_idft_rng", seed, r0, R, P, Nf, dv.ptr(T), 608, npts, dv.ptr(G_rng), npts, gpu["s"])
+    w = dv.empty((R * P, 2 * Nf))
+    for r in range(R):
+        for a in range(P):
+            lib.call("pta_rng_fill_normal", seed, r0 + r, 1, philox_ref.stream_id(1, a), Nf, 1,
+                     ctypes.c_void_p(w.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, gpu["s"])
+    G_rep = dv.zeros((R * P, npts))
+    lib.call("pta_gwb_idft", dv.ptr(w), 2 * Nf, R * P, Nf, dv.ptr(T), 608, npts, dv.ptr(G_rep), npts, 1, gpu["s"])
+    a, b = G_rng.cpu().numpy(), G_rep.cpu().numpy()
+    assert np.max(np.abs(a - b)) < 1e-12 * np.max(np.abs(b))
+    # and the host twin of the draws
+    z0, z1 = philox_ref.normal_pairs(seed, r0 + 2, philox_ref.stream_id(1, 4), Nf)
+    wr = w.cpu().numpy()[2 * P + 4]
+    assert np.max(np.abs(wr[0::2] - z0)) < 1e-13 and np.max(np.abs(wr[1::2] - z1)) < 1e-13
+
+
+def test_td_mode_against_oracle(gpu):
+    """dense path: covariance assembly -> blocked Cholesky -> L z, vs numpy on the same recipe and draws."""
+    from pta_replicator_amd import red_noise as rn
+    dv, lib = gpu["dv"], gpu["lib"]
+    rng = np.random.default_rng(11)
+    N, nm, R = 333, 30, 6
+    t = np.sort(rng.uniform(53000, 58000, N)) * 86400.0
+    epoch_of, ne, first, _ = po.quantize(t / 86400.0, dt=20.0)
+    sig2 = rng.uniform(1e-14, 4e-14, N)
+    ec = rng.uniform(1e-7, 3e-7, ne)
+    Cref = po.td_covariance(t, -13.5, 3.3, nm, sig2, epoch_of, ec)
+    Tspan = t.max() - t.min()
+    f = np.arange(1, nm + 1) / Tspan
+    Ft = dv.empty((2 * nm, N))
+    lib.call("pta_rn_basis", dv.ptr(dv.f64(t)), N, 0.0, dv.ptr(dv.f64(f)), None, nm, 0, dv.ptr(Ft), N, gpu["s"])
+    phi = po.red_noise_prior(np.repeat(f, 2), -13.5, 3.3, Tspan)
+    Cd = dv.zeros((N, N))
+    lib.call("pta_td_cov_assemble", dv.ptr(Ft), N, N, 2 * nm, dv.ptr(dv.f64(phi)), dv.ptr(dv.f64(sig2)), dv.ptr(dv.i32(epoch_of)),
+             dv.ptr(dv.f64((ec ** 2)[epoch_of])), dv.ptr(Cd), N, gpu["s"])
+    lo = np.tril_indices(N)
+    assert np.max(np.abs(Cd.cpu().numpy()[lo] - Cref[lo])) < 1e-10 * np.max(np.abs(Cref))
+    L = rn.cholesky_device(Cd)
+    Lref = np.linalg.cholesky(Cref)
+    assert np.max(np.abs(L.cpu().numpy() - Lref)) < 1e-8 * np.max(np.abs(Lref))
+    z = rng.standard_normal((R, N))
+    out = dv.zeros((R, N))
+    lib.call("pta_td_trmm", dv.ptr(L), N, N, dv.ptr(dv.f64(z)), N, R, dv.ptr(out), N, 0, gpu["s"])
+    ref = po.td_draw(Cref, z.T).T
+    assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-8 * np.sqrt(np.mean(ref ** 2))

@@ -1,0 +1,164 @@
+"""CPU tests of the host side of the boundary: native epoch bucketing, host-side scalar formulas, the array-backed
+pulsar container, error conventions.  (No GPU: nothing here launches a kernel.)"""
+import numpy as np
+import pytest
+
+from helpers import load, mjd_ld
+from oracle import pta_oracle as po
+
+
+def test_native_quantize_matches_reference_structure():
+    from pta_replicator_amd.white_noise import epoch_map
+    z = load("c2_b1855.npz")
+    mjd = (z["mjd_hi"].astype(np.longdouble) + z["mjd_lo"].astype(np.longdouble)).astype(np.float64)
+    toa_flags = z["backends"][z["flag_index"]]
+    epoch_of, first = epoch_map(mjd, 0.1)   # real, unsorted tim file
+    assert np.array_equal(epoch_of, z["cg01_epoch_of"])
+    assert np.array_equal(toa_flags[first], z["cg01_aveflags"])
+    epoch_of, first = epoch_map(mjd, 1.0 / 86400.0)
+    assert len(first) == int(z["cg1s_n_epochs"]) and np.array_equal(epoch_of, z["cg1s_epoch_of"])
+
+
+@pytest.mark.parametrize("n,dt", [(1, 0.1), (2, 0.1), (1000, 0.05), (5000, 0.1), (777, 10.0)])
+def test_native_quantize_matches_oracle(n, dt):
+    from pta_replicator_amd.white_noise import epoch_map, quantize_fast
+    rng = np.random.default_rng(n)
+    t = rng.uniform(53000, 53000 + n * 0.07, n)
+    if n > 10:
+        t[5] = t[6]  # a tie
+    epoch_of, first = epoch_map(t, dt)
+    eo, ne, fo, ave = po.quantize(t, dt=dt)
+    assert np.array_equal(epoch_of, eo) and np.array_equal(first, fo)
+    avetoas, U = quantize_fast(t, dt=dt)
+    assert U.shape == (n, ne) and np.all(U.sum(axis=1) == 1) and np.allclose(avetoas, ave)
+    assert np.array_equal(np.argmax(U, axis=1), eo)
+
+
+def test_quantize_stable_sort_path_and_bad_arguments():
+    import ctypes
+    from pta_replicator_amd import _lib, device as dv
+    t = np.array([3.0, 1.0, 1.04, 2.0, 1.11, 3.05])
+    eo = np.empty(6, dtype=np.int32); fi = np.empty(6, dtype=np.int32); ne = ctypes.c_int(0)
+    _lib.call("pta_quantize_epochs", dv.hptr(t), 6, 0.1, None, dv.hptr(eo), dv.hptr(fi), ctypes.byref(ne))
+    assert ne.value == 4 and list(eo) == [3, 0, 0, 2, 1, 3] and list(fi[:4]) == [1, 4, 3, 0]
+    bad = np.array([0, 1, 2, 3, 4, 99], dtype=np.int64)
+    with pytest.raises(_lib.PtaError):
+        _lib.call("pta_quantize_epochs", dv.hptr(t), 6, 0.1, dv.hptr(bad), dv.hptr(eo), dv.hptr(fi), ctypes.byref(ne))
+
+
+def _array_psrs(z, prefix, P):
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    out = []
+    for i in range(P):
+        p = SimulatedPulsar(toas=ArrayTOAs(mjd_ld(z, prefix, i), z[f"{prefix}err_us_{i}"]), name=str(z[prefix + "names"][i]),
+                            loc={"RAJ": float(z[prefix + "raj_hours"][i]), "DECJ": float(z[prefix + "decj_deg"][i])})
+        make_ideal(p)
+        out.append(p)
+    return out
+
+
+@pytest.mark.parametrize("tag", ["raw_", "nudged_"])
+def test_gwb_grid_knife_edge_is_reproduced_on_the_host(tag):
+    """Nf = 3001 on the raw tim-file MJDs, 3000 after a 1 us nudge: computed with the reference's
+    own NumPy expressions, never re-derived on the device."""
+    from pta_replicator_amd.red_noise import gwb_spectrum, gwb_time_grid
+    z = load("c1_small.npz")
+    psrs = _array_psrs(z, tag, 3)
+    grid = gwb_time_grid(psrs)
+    assert grid["Nf"] == int(z[tag + "Nf"])
+    og = po.gwb_grid([float(mjd_ld(z, tag, i).min()) for i in range(3)], [float(mjd_ld(z, tag, i).max()) for i in range(3)])
+    assert np.array_equal(grid["f"], og["f"]) and np.array_equal(grid["ut"], og["ut"]) and grid["dt"] == og["dt"]
+    C = gwb_spectrum(grid["f"], grid["dur"], 10, -14, 4.33)
+    assert np.array_equal(C, po.gwb_spectrum(og["f"], og["dur"], 10, -14, 4.33))
+
+
+def test_gwb_spectrum_branches_match_oracle():
+    from pta_replicator_amd.red_noise import gwb_spectrum
+    z = load("variants.npz")
+    f = np.arange(0, 1e-6, 3e-10); f[0] = f[1]
+    for kw in (dict(turnover=True, f0=3e-9, beta=1.2, power=2.0), dict(userSpec=z["userSpec"]), dict()):
+        a = gwb_spectrum(f, 3e8, 10, -14.2, 13. / 3., **kw)
+        b = po.gwb_spectrum(f, 3e8, 10, -14.2, 13. / 3., **kw)
+        assert np.max(np.abs(a - b) / b) < 1e-13
+
+
+def test_cgw_parameters_reproduce_the_oracle_waveform_on_the_host():
+    """the 18 scalars handed to pta_cgw, pushed through a NumPy twin of the kernel body, equal oracle cgw_dt."""
+    from pta_replicator_amd.deterministic import cgw_parameters
+    mjd = np.linspace(53000, 57000, 50)
+    base = dict(gwtheta=1.1, gwphi=4.0, mc=3e9, dist=40.0, fgw=2.2e-8, phase0=1.3, psi=0.4, inc=1.0, tref=53000 * 86400)
+    for kw in (dict(pdist=1.3), dict(pdist=0.9, evolve=False, phase_approx=True), dict(pdist=1.1, evolve=False), dict(psrTerm=False),
+               dict(pphase=2.1)):
+        par, _, _, _ = cgw_parameters(0.7, 2.2, **base, **kw)
+        tref, w0, ph0, w053, fac1, fac2, fac3, i1, i2, c2p, s2p, fp, fc, pdt = par[:14]
+        toas = mjd * 86400 - tref
+        tp = toas - pdt
+        mode = int(par[14])
+        if mode == 0:
+            om, omp = w0 * (1 - fac1 * toas) ** (-3 / 8), w0 * (1 - fac1 * tp) ** (-3 / 8)
+            ph, php = ph0 + fac2 * (w053 - om ** (-5 / 3)), ph0 + fac2 * (w053 - omp ** (-5 / 3))
+        elif mode == 1:
+            om, omp = w0, par[16]
+            ph, php = ph0 + om * toas, par[17] + omp * toas
+        else:
+            om = omp = w0
+            ph, php = ph0 + om * toas, ph0 + om * tp
+        At, Bt, Atp, Btp = np.sin(2 * ph) * i1, np.cos(2 * ph) * i2, np.sin(2 * php) * i1, np.cos(2 * php) * i2
+        al, alp = fac3 / om ** (1 / 3), fac3 / omp ** (1 / 3)
+        rp, rc = al * (At * c2p + Bt * s2p), al * (-At * s2p + Bt * c2p)
+        rpp, rcp = alp * (Atp * c2p + Btp * s2p), alp * (-Atp * s2p + Btp * c2p)
+        res = fp * (rpp - rp) + fc * (rcp - rc) if par[15] else -fp * rp - fc * rc
+        ref = po.cgw_dt(mjd, 0.7, 2.2, **base, **kw)
+        assert np.max(np.abs(res - ref)) <= 1e-15 * np.max(np.abs(ref))
+
+
+def test_array_pulsar_bookkeeping():
+    from pta_replicator_amd._compat import TimeDelta, u
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    toas = ArrayTOAs(np.array([53000.0, 53010.0, 53020.0]), [0.5, 1.0, 2.0], [{"f": "a"}, {"f": "b"}, {"f": "a"}])
+    psr = SimulatedPulsar(toas=toas, name="J0000+0000", loc={"RAJ": 1.0, "DECJ": 2.0})
+    with pytest.raises(ValueError, match="make_ideal"):
+        psr.update_added_signals("x", {})
+    make_ideal(psr)
+    dt = np.array([1e-6, -2e-6, 3e-6]) * u.s
+    psr.update_added_signals("J0000+0000_x", {"p": 1}, dt)
+    with pytest.raises(ValueError, match="already exists"):
+        psr.update_added_signals("J0000+0000_x", {})
+    psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
+    psr.update_residuals()
+    w = 1 / np.array([0.5, 1.0, 2.0]) ** 2
+    expect = dt.value - np.sum(dt.value * w) / np.sum(w)
+    assert np.max(np.abs(psr.residuals.resids_value - expect)) < 2e-12   # longdouble MJD resolution ~ 5e-12 s
+    assert psr.toas.ntoas == 3 and psr.toas.get_errors().to("s").value[1] == 1.0 * 1e-6
+    assert psr.toas.first_MJD.value == 53000.0 + float(np.longdouble(1e-6) / 86400) or abs(psr.toas.first_MJD.value - 53000.0) < 1e-9
+    make_ideal(psr)
+    assert np.all(psr.residuals.resids_value == 0) and psr.added_signals == {}
+
+
+def test_par_tim_readers(tmp_path):
+    from pta_replicator_amd.simulate import load_from_directories, load_pulsar, read_par_location
+    par = tmp_path / "par"; tim = tmp_path / "tim"; par.mkdir(); tim.mkdir()
+    (par / "A.par").write_text("PSR  J1234+5678\nRAJ  12:34:56.7 1\nDECJ  -56:07:08.9 1\nF0 100 1\n")
+    (par / "B.par").write_text("PSR  B1855+09\nELONG  286.86 1\nELAT  32.32 1\n")
+    for nm in ("A", "B"):
+        (tim / f"{nm}.tim").write_text("FORMAT 1\nMODE 1\n x 1440.0 53000.000000000123 0.5 AXIS -f L-wide_ASP -be ASP\n"
+                                       "C comment\n y 1440.0 53030.5 1.25 AXIS -f 430_PUPPI -pn -12.0\n")
+    name, loc = read_par_location(str(par / "A.par"))
+    assert name == "J1234+5678" and abs(loc["RAJ"] - (12 + 34 / 60 + 56.7 / 3600)) < 1e-12 and abs(loc["DECJ"] + (56 + 7 / 60 + 8.9 / 3600)) < 1e-12
+    psrs = load_from_directories(str(par), str(tim))
+    assert [p.name for p in psrs] == ["J1234+5678", "B1855+09"] and psrs[1].loc == {"ELONG": 286.86, "ELAT": 32.32}
+    t = psrs[0].toas
+    assert t.ntoas == 2 and t.flags[0] == {"f": "L-wide_ASP", "be": "ASP"} and t.flags[1]["f"] == "430_PUPPI"
+    assert list(t.errors_us) == [0.5, 1.25] and float(t.mjd_ld[1]) == 53030.5
+    with pytest.raises(FileNotFoundError):
+        load_pulsar(str(par / "nope.par"), str(tim / "A.tim"))
+
+
+def test_ecliptic_branch_restatement_is_sane():
+    """ELONG/ELAT -> RA/DEC (PARITY UNPINNED: pyephem absent). Sanity: B1855+09 and J1909-3744 land on their
+    catalogue positions to a few arcseconds."""
+    from pta_replicator_amd._position import ecliptic_to_equatorial
+    ra, dec = ecliptic_to_equatorial(284.2208542340, -15.1555138035, "J1909-3744")
+    assert abs(np.degrees(ra) / 15 - (19 + 9 / 60 + 47.4 / 3600)) < 1e-3 and abs(np.degrees(dec) + (37 + 44 / 60 + 14.5 / 3600)) < 2e-3
+    ra, dec = ecliptic_to_equatorial(286.863485782621126, 32.321482985635249, "B1855+09")  # B name -> epoch 1950
+    assert abs(np.degrees(ra) / 15 - (18 + 55 / 60 + 13.7 / 3600)) < 2e-3 and abs(np.degrees(dec) - (9 + 39 / 60 + 13 / 3600)) < 5e-3

@@ -1,0 +1,101 @@
+"""CPU checks of the device math: the __host__ __device__ headers under pta_replicator_amd/csrc are
+compiled with g++ (tests/hostcheck/hostcheck.cpp) and compared with known answers, the oracle and the
+reference-generated golden vectors.  The same formulas run on the GPU in the -m gpu tests."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import load
+from oracle import philox_ref
+from oracle import pta_oracle as po
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def hc(tmp_path_factory):
+    out = tmp_path_factory.mktemp("hostcheck") / "libhostcheck.so"
+    src = os.path.join(HERE, "hostcheck", "hostcheck.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", str(out)])
+    lib = ctypes.CDLL(str(out))
+    lib.hc_stream_id.restype = ctypes.c_uint32
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+# Random123 known-answer vectors for philox4x32-10 (kat_vectors of the Random123 distribution)
+KAT = [
+    ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+    ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+    ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0], [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+]
+
+
+@pytest.mark.parametrize("ctr,key,expect", KAT)
+def test_philox_known_answers(hc, ctr, key, expect):
+    c = np.array(ctr, dtype=np.uint32); k = np.array(key, dtype=np.uint32); o = np.zeros(4, dtype=np.uint32)
+    hc.hc_philox(_p(c, ctypes.c_uint32), _p(k, ctypes.c_uint32), _p(o, ctypes.c_uint32))
+    assert [int(x) for x in o] == expect
+    assert [int(x) for x in philox_ref.philox4x32_10(c[None, :], k)[0]] == expect
+
+
+def test_normals_match_numpy_twin(hc):
+    """device formula (compiled for the host) == the NumPy twin used to replay throughput-mode draws."""
+    seed, r, npairs = 0x1234567890ABCDEF, 7, 4096
+    stream = hc.hc_stream_id(3, 11)
+    assert stream == philox_ref.stream_id(3, 11)
+    out = np.zeros(2 * npairs)
+    hc.hc_normal_pairs(ctypes.c_uint64(seed), ctypes.c_uint64(r), ctypes.c_uint32(stream), npairs, _p(out, ctypes.c_double))
+    z0, z1 = philox_ref.normal_pairs(seed, r, stream, npairs)
+    assert np.max(np.abs(out[0::2] - z0)) < 1e-14 and np.max(np.abs(out[1::2] - z1)) < 1e-14
+    u = np.zeros(2 * npairs)
+    hc.hc_uniform_pairs(ctypes.c_uint64(seed), ctypes.c_uint64(r), ctypes.c_uint32(stream), npairs, _p(u, ctypes.c_double))
+    u1, u2 = philox_ref.uniform_pairs(seed, r, stream, npairs)
+    assert np.array_equal(u[0::2], u1) and np.array_equal(u[1::2], u2)
+    assert u[0::2].min() > 0.0 and u[0::2].max() <= 1.0 and u[1::2].min() >= 0.0 and u[1::2].max() < 1.0
+
+
+def test_normals_are_standard_normal(hc):
+    npairs = 200000
+    out = np.zeros(2 * npairs)
+    hc.hc_normal_pairs(ctypes.c_uint64(99), ctypes.c_uint64(0), ctypes.c_uint32(1 << 24), npairs, _p(out, ctypes.c_double))
+    n = out.size
+    assert abs(out.mean()) < 5 / np.sqrt(n)
+    assert abs(out.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(np.mean(out ** 4) - 3) < 5 * np.sqrt(96 / n)
+    assert abs(np.corrcoef(out[0::2], out[1::2])[0, 1]) < 5 / np.sqrt(npairs)
+    assert abs(np.corrcoef(out[:-1], out[1:])[0, 1]) < 5 / np.sqrt(n)
+
+
+def test_orf_basis_device_math_vs_reference_golden(hc):
+    z = load("orf_basis.npz")
+    locs = np.ascontiguousarray(z["psr_locs"], dtype=np.float64)
+    P, lmax = len(locs), int(z["lmax"])
+    basis = np.zeros(((lmax + 1) ** 2, P, P))
+    hc.hc_orf_basis(_p(locs, ctypes.c_double), P, lmax, _p(basis, ctypes.c_double))
+    ref = z["basis"]
+    scale = np.max(np.abs(ref), axis=(1, 2), keepdims=True)
+    assert np.max(np.abs(basis - ref) / scale) < 1e-11
+    orf = np.zeros((P, P))
+    hc.hc_orf_hd(_p(locs, ctypes.c_double), P, _p(orf, ctypes.c_double))
+    assert np.max(np.abs(orf - 2 * np.sqrt(4 * np.pi) * ref[0])) < 1e-14
+    assert np.max(np.abs(orf - po.hd_orf_closed_form(locs))) < 1e-14
+
+
+def test_orf_hd_headline_array(hc):
+    """68 isotropic pulsars (config 3 geometry): closed form == general basis, and is positive definite."""
+    rng = np.random.default_rng(68)
+    locs = np.stack([rng.uniform(0, 24, 68) * np.pi / 12, np.pi / 2 - np.arcsin(rng.uniform(-1, 1, 68))], axis=1)
+    orf = np.zeros((68, 68))
+    hc.hc_orf_hd(_p(locs, ctypes.c_double), 68, _p(orf, ctypes.c_double))
+    assert np.max(np.abs(orf - po.hd_orf_closed_form(locs))) < 1e-14
+    basis = np.zeros((1, 68, 68))
+    hc.hc_orf_basis(_p(locs, ctypes.c_double), 68, 0, _p(basis, ctypes.c_double))
+    assert np.max(np.abs(2 * np.sqrt(4 * np.pi) * basis[0] - orf)) < 1e-13
+    np.linalg.cholesky(orf)
