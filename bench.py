@@ -188,7 +188,7 @@ def main():
 
     import ctypes
     timed("pta_engine_rn_coef", lambda: _lib.call("pta_engine_rn_coef", eng.seed, 0, R, P, eng.K, dv.ptr(eng.d_amp), dv.ptr(ws["coef"]), s))
-    timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_T), eng.ldt, npts, dv.ptr(ws["G0"]), npts, s))
+    timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts, s))
     timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s))
     timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
 
@@ -212,7 +212,7 @@ def main():
     n_fft = 2 * Nf - 2
     alg_bytes = 8.0 * eng.n_toa * R
     alg_flops_gwb = (4.0 * P * P * Nf + 5.0 * n_fft * np.log2(n_fft) * P) * R
-    exe_flops_gwb = 2.0 * (R * P) * (2.0 * (Nf - 2)) * npts       # what the pruned-DFT GEMM actually executes
+    exe_flops_gwb = 2.0 * (R * P) * (2.0 * (Nf - 2)) * ((npts + 1) // 2)  # what the symmetric pruned-DFT GEMM executes
     dom = max(("pta_gwb_idft_rng", "pta_engine_synth"), key=lambda k: kern[k])
     if dom == "pta_engine_synth":
         ach = alg_bytes / (kern[dom] * 1e-3) / 1e9

@@ -132,9 +132,19 @@ int pta_gwb_twiddle(const double *sqrtC, int Nf, int npts, int i0, double inv_dt
 int pta_gwb_idft(const double *w, int64_t ldw, int M, int Nf, const double *T, int64_t ldt, int npts, double *G0,
                  int64_t ldg, int algo, void *stream);
 
-/* Same with w generated on chip: row m = r*P + a uses stream (GWB, a) of realisation r0 + r,
- * pair k -> (Re, Im) of w[a,k] (red_noise.py:238-240).                                     */
-int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *T, int64_t ldt, int npts,
+/* Throughput mode: same transform with w generated on chip - row m = r*P + a uses stream (GWB, a) of
+ * realisation r0 + r, pair k -> (Re, Im) of w[a,k] (red_noise.py:238-240) - and with the output window's
+ * mirror symmetry exploited:  x[c + j'] = E - O, x[c - j'] = E + O  around the window centre c, which
+ * halves the flops.  pta_gwb_twiddle_sym lays the half-window twiddles out slab by slab exactly as the
+ * kernel stages them through LDS (Tsym) plus the per-bin rotation e^{2 pi i c k / n} (rot); sizes in doubles
+ * come from pta_gwb_twiddle_sym_size.  pta_set_idft_variant selects the column tiling of a workgroup:
+ * 0 = 19 tiles of 16 (the whole half window of npts = 600, one wave per SIMD), 1 (default) = 10 tiles
+ * (two chunks, two waves per SIMD), 2 = 7 tiles (three chunks); choose before sizing/building Tsym. */
+int pta_set_idft_variant(int variant);
+int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int64_t *rot_doubles);
+int pta_gwb_twiddle_sym(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *Tsym, double *rot,
+                        void *stream);
+int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot, int npts,
                      double *G0, int64_t ldg, void *stream);
 
 /* G[r,a,:] = sum_b Mchol[a,b] G0[r,b,:]  (the M@w of red_noise.py:268, applied after the DFT). */

@@ -70,109 +70,203 @@ extern "C" int pta_gwb_idft(const double *w, int64_t ldw, int M, int Nf, const d
 }
 
 // ---- throughput mode: the draws never exist in memory -------------------------------------------
-// Workgroup = 4 waves = 64 rows (row m = realisation r * P + pulsar a) x all output samples.  Wave w
-// owns rows [16w, 16w+16) and all NT column tiles: NT x 4 fp64 accumulators per lane (304 VGPRs at
-// NT = 38, one wave per SIMD).  Per K-step of 4 frequency bins a lane is A-operand element
-// (row l & 15, bin l >> 4) of v_mfma_f64_16x16x4_f64 - i.e. exactly ONE complex draw w[a, k], which
-// it generates in registers (Philox + Box-Muller) and feeds to two MFMAs per column tile: Re against
-// the cos plane, Im against the sin plane.  The T slab of the K-step (4 rows x 2 planes) is shared by
-// the 4 waves through LDS, double buffered; T itself streams from L2 (all workgroups of an XCD walk it
-// in lock-step, so HBM sees it once).
-#define IR_NT 38             // column tiles of 16 -> up to 608 output samples per pass
-#define IR_LD (IR_NT * 16)   // columns of a slab row
-#define IR_PITCH (IR_LD + 16) // LDS row pitch == 16 (mod 32) doubles: the 2 k-rows a 32-lane group reads hit disjoint banks
-#define IR_SLAB (2 * 4 * IR_LD)    // elements of one K-step slab: [plane][k][col]
-#define IR_BUF (2 * 4 * IR_PITCH)  // doubles of one LDS buffer
+// Two ideas on top of "DFT as GEMM":
+//
+// (1) Window symmetry halves the flops.  With c the centre of the output window and j = c + j',
+//         x[c + j'] = E(j') - O(j'),   x[c - j'] = E(j') + O(j'),
+//         E(j') = sum_k amp_k a'_k cos(2 pi j' k / n),   O(j') = sum_k amp_k b'_k sin(2 pi j' k / n),
+//     where (a'_k + i b'_k) = (Re w_k + i Im w_k) e^{2 pi i c k / n} is the draw rotated by a fixed,
+//     realisation-independent phase.  So npts outputs cost two [rows x Kf] . [Kf x npts/2] products.
+//
+// (2) The A operand never touches memory.  Workgroup = 4 waves = 64 rows (row m = realisation r * P +
+//     pulsar a) x NT column tiles of the half window.  Per K-step of 4 frequency bins a lane is A-operand
+//     element (row l & 15, bin l >> 4) of v_mfma_f64_16x16x4_f64 - exactly ONE complex draw w[a, k], which
+//     it generates in registers (Philox + Box-Muller), rotates, and feeds to the E tiles (Re') and the O
+//     tiles (Im').  The twiddle slab of the K-step (2 planes x 4 bins x NT*16 columns) is pre-laid-out in
+//     global memory exactly as it sits in LDS, shared by the 4 waves, double buffered; all workgroups of an
+//     XCD walk it in lock-step, so it streams from L2 and HBM sees it once.
+template <int NT>
+struct pta_sym_cfg {
+  static constexpr int COLS = NT * 16;
+  // LDS/global row pitch == 16 (mod 32) doubles: the two bins a 32-lane group reads land on disjoint banks
+  static constexpr int PITCH = (NT % 2) ? COLS : COLS + 16;
+  static constexpr int SLAB = 8 * PITCH;               // doubles per K-step: [plane 2][bin 4][PITCH]
+  static constexpr int NLD = (SLAB / 2 + 255) / 256;   // double2 loads per thread per slab
+  static constexpr int SLAB_PAD = NLD * 512;           // slab stride, padded so that the staging copy needs no guards
+};
 
-__global__ __launch_bounds__(256, 1) void k_gwb_idft_rng(uint64_t seed, uint64_t r0, int M, int P, int Nf,
-                                                         const double *__restrict__ T, int64_t ldt, int npts, int col0,
-                                                         double *__restrict__ G0, int64_t ldg) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 buffers x [2 planes][4 k][IR_PITCH]
+// Tsym[chunk][ks][plane][kk][PITCH] and rot[(ks*4+kk)*2 + {0,1}] = (cos, sin)(2 pi c k / n), zero padded.
+template <int NT>
+__global__ void k_gwb_twiddle_sym(const double *__restrict__ sqrtC, int Nf, int npts, int i0, double inv_dt,
+                                  double *__restrict__ Tsym, double *__restrict__ rot) {
+  using C = pta_sym_cfg<NT>;
+  const int Kf = Nf - 2, nstep = (Kf + 3) >> 2;
+  const int half = (npts + 1) >> 1;
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;  // column inside the chunk, < PITCH
+  const int kq = blockIdx.y;                               // padded bin index, < nstep*4
+  const int chunk = blockIdx.z;
+  if (col >= C::PITCH) return;
+  const int64_t n = 2 * (int64_t)Nf - 2;
+  const int p = chunk * C::COLS + col;
+  double c = 0.0, s = 0.0;
+  if (kq < Kf && col < C::COLS && p < half) {
+    int64_t twoj = (npts & 1) ? 2 * (int64_t)p : 2 * (int64_t)p + 1;  // 2 j'
+    int64_t m2 = (twoj * (int64_t)(kq + 1)) % (2 * n);
+    double sn, cs;
+    sincospi((double)m2 / (double)n, &sn, &cs);
+    double amp = 2.0 * inv_dt / (double)n * sqrtC[kq + 1];
+    c = amp * cs;
+    s = amp * sn;
+  }
+  const int ks = kq >> 2, kk = kq & 3;
+  double *slab = Tsym + ((int64_t)chunk * nstep + ks) * C::SLAB_PAD;
+  slab[(0 * 4 + kk) * C::PITCH + col] = c;
+  slab[(1 * 4 + kk) * C::PITCH + col] = s;
+  if (chunk == 0 && col == 0) {
+    double sn = 0.0, cs = 0.0;
+    if (kq < Kf) {
+      int64_t m2 = ((2 * (int64_t)i0 + npts - 1) * (int64_t)(kq + 1)) % (2 * n);  // 2 c k mod 2n
+      sincospi((double)m2 / (double)n, &sn, &cs);
+    }
+    rot[2 * kq] = cs;
+    rot[2 * kq + 1] = sn;
+  }
+}
+
+template <int NT, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_gwb_idft_sym_rng(uint64_t seed, uint64_t r0, int M, int P, int Nf,
+                                                                const double *__restrict__ Tsym,
+                                                                const double *__restrict__ rot, int npts,
+                                                                double *__restrict__ G0, int64_t ldg) {
+  using C = pta_sym_cfg<NT>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x SLAB_PAD
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
-  const int Kf = Nf - 2;
-  const int ncol = min(npts - col0, IR_LD);
-  const int ntile = (ncol + 15) >> 4;
+  const int Kf = Nf - 2, nstep = (Kf + 3) >> 2;
+  const int chunk = blockIdx.y;
   const int m = blockIdx.x * 64 + wv * 16 + (l & 15);
   const int mr = min(m, M - 1);
   const uint64_t real = r0 + (uint64_t)(mr / P);
   const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(mr % P));
-  pta_f64x4 acc[IR_NT];
+  pta_f64x4 accE[NT], accO[NT];
 #pragma unroll
-  for (int i = 0; i < IR_NT; ++i) acc[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
-
-  const int nstep = (Kf + 3) >> 2;
-  // slab loader: element e of the slab = (plane, k, col); 19 elements per thread
-  auto load_slab = [&](int ks, double *regs) {
+  for (int i = 0; i < NT; ++i) {
+    accE[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    accO[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  const double2 *src = reinterpret_cast<const double2 *>(Tsym + (int64_t)chunk * nstep * C::SLAB_PAD) + t;
+  double2 *lds2 = reinterpret_cast<double2 *>(lds) + t;
+  double2 regs[C::NLD];
 #pragma unroll
-    for (int q = 0; q < IR_SLAB / 256; ++q) {
-      int e = q * 256 + t;
-      int col = e % IR_LD, pk = e / IR_LD;  // pk = plane*4 + k
-      int kq = ks * 4 + (pk & 3);
-      bool ok = (kq < Kf) && (col < ncol);
-      regs[q] = ok ? T[((int64_t)(pk >> 2) * Kf + kq) * ldt + col0 + col] : 0.0;
-    }
-  };
-  auto store_slab = [&](double *buf, const double *regs) {
-#pragma unroll
-    for (int q = 0; q < IR_SLAB / 256; ++q) {
-      int e = q * 256 + t;
-      buf[(e / IR_LD) * IR_PITCH + (e % IR_LD)] = regs[q];
-    }
-  };
-  double regs[IR_SLAB / 256];
-  load_slab(0, regs);
-  store_slab(lds, regs);
+  for (int q = 0; q < C::NLD; ++q) lds2[q * 256] = src[q * 256];
   __syncthreads();
+  const int kk = l >> 4;
   for (int ks = 0; ks < nstep; ++ks) {
-    double *cur = lds + (ks & 1) * IR_BUF;
-    double *nxt = lds + ((ks + 1) & 1) * IR_BUF;
-    if (ks + 1 < nstep) load_slab(ks + 1, regs);  // global loads in flight under the MFMAs below
+    const double *cur = lds + (ks & 1) * C::SLAB_PAD;
+    double2 *nxt = lds2 + ((ks + 1) & 1) * (C::SLAB_PAD / 2);
+    // next slab: global loads fly under the MFMAs below (the last step harmlessly re-stages its own slab,
+    // which keeps the staging registers free of control flow)
+    const int ksn = min(ks + 1, nstep - 1);
+#pragma unroll
+    for (int q = 0; q < C::NLD; ++q) regs[q] = src[(int64_t)ksn * (C::SLAB_PAD / 2) + q * 256];
     double re, im;
-    pta_normal_pair(seed, real, strm, (uint32_t)(ks * 4 + (l >> 4) + 1), re, im);  // pair k <-> w[a,k]
-    const double *bc = cur + (l >> 4) * IR_PITCH + (l & 15);
-    const double *bs = bc + 4 * IR_PITCH;
-    // two sweeps over the tiles so that consecutive MFMAs never share an accumulator
+    pta_normal_pair(seed, real, strm, (uint32_t)(ks * 4 + kk + 1), re, im);  // pair k <-> w[a,k] (red_noise.py:240)
+    const double2 cs = reinterpret_cast<const double2 *>(rot)[ks * 4 + kk];
+    const double ar = re * cs.x - im * cs.y;  // rotated draw
+    const double br = re * cs.y + im * cs.x;
+    const double *bc = cur + kk * C::PITCH + (l & 15);
+    const double *bs = bc + 4 * C::PITCH;
 #pragma unroll
-    for (int i = 0; i < IR_NT; ++i)
-      if (i < ntile) acc[i] = pta_mfma_f64(re, bc[i * 16], acc[i]);
+    for (int i = 0; i < NT; ++i) accE[i] = pta_mfma_f64(ar, bc[i * 16], accE[i]);
 #pragma unroll
-    for (int i = 0; i < IR_NT; ++i)
-      if (i < ntile) acc[i] = pta_mfma_f64(im, bs[i * 16], acc[i]);
-    if (ks + 1 < nstep) store_slab(nxt, regs);
+    for (int i = 0; i < NT; ++i) accO[i] = pta_mfma_f64(br, bs[i * 16], accO[i]);
+#pragma unroll
+    for (int q = 0; q < C::NLD; ++q) nxt[q * 256] = regs[q];
     __syncthreads();
   }
+  const int half = (npts + 1) >> 1;
+  const int hi0 = npts >> 1;                         // even: c + 1/2 ; odd: the centre sample
+  const int lo0 = (npts & 1) ? hi0 : hi0 - 1;
 #pragma unroll
-  for (int i = 0; i < IR_NT; ++i) {
-    if (i < ntile) {
+  for (int i = 0; i < NT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = blockIdx.x * 64 + wv * 16 + pta_mfma_row(l, r);
-        int col = i * 16 + pta_mfma_col(l);
-        if (row < M && col < ncol) G0[(int64_t)row * ldg + col0 + col] = acc[i][r];
+    for (int r = 0; r < 4; ++r) {
+      int row = blockIdx.x * 64 + wv * 16 + pta_mfma_row(l, r);
+      int p = chunk * C::COLS + i * 16 + pta_mfma_col(l);
+      if (row < M && p < half) {
+        double e = accE[i][r], o = accO[i][r];
+        G0[(int64_t)row * ldg + hi0 + p] = e - o;
+        G0[(int64_t)row * ldg + lo0 - p] = e + o;
       }
     }
   }
 }
 
-extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *T, int64_t ldt, int npts,
-                                double *G0, int64_t ldg, void *stream) {
-  PTA_REQUIRE(T && G0, PTA_E_ARG, "pta_gwb_idft_rng: NULL argument");
-  PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && Nf >= 3 && npts > 0 && ldt >= npts && ldg >= npts, PTA_E_ARG,
+static int g_idft_variant = 1;  // 0: NT = 19 (whole half window per workgroup, 1 wave/SIMD), 1: NT = 10 (2 chunks, 2 waves/SIMD), 2: NT = 7 (3 chunks)
+extern "C" int pta_set_idft_variant(int v) {
+  g_idft_variant = v;
+  return PTA_OK;
+}
+
+static int sym_nt() { return g_idft_variant == 1 ? 10 : (g_idft_variant == 2 ? 7 : 19); }
+static int sym_pitch(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }
+static int sym_slab_pad(int nt) { return ((8 * sym_pitch(nt) / 2 + 255) / 256) * 512; }
+
+extern "C" int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int64_t *rot_doubles) {
+  const int nt = sym_nt();
+  const int nstep = (Nf - 2 + 3) >> 2;
+  const int half = (npts + 1) >> 1;
+  const int nchunk = (half + nt * 16 - 1) / (nt * 16);
+  if (rot_doubles) *rot_doubles = (int64_t)nstep * 8;
+  return (int64_t)nchunk * nstep * sym_slab_pad(nt);
+}
+
+extern "C" int pta_gwb_twiddle_sym(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *Tsym, double *rot,
+                                   void *stream) {
+  PTA_REQUIRE(sqrtC && Tsym && rot, PTA_E_ARG, "pta_gwb_twiddle_sym: NULL argument");
+  PTA_REQUIRE(Nf >= 3 && npts > 0 && i0 >= 0, PTA_E_ARG, "pta_gwb_twiddle_sym: Nf=%d npts=%d", Nf, npts);
+  const int nt = sym_nt();
+  const int nstep = (Nf - 2 + 3) >> 2;
+  const int half = (npts + 1) >> 1;
+  const int nchunk = (half + nt * 16 - 1) / (nt * 16);
+  PTA_REQUIRE(nstep * 4 <= 65535 && nchunk <= 65535, PTA_E_ARG, "pta_gwb_twiddle_sym: problem too large");
+  dim3 g(pta_cdiv(sym_pitch(nt), 64), nstep * 4, nchunk);
+  if (nt == 19)
+    hipLaunchKernelGGL(k_gwb_twiddle_sym<19>, g, dim3(64), 0, pta_stream(stream), sqrtC, Nf, npts, i0, inv_dt, Tsym, rot);
+  else if (nt == 10)
+    hipLaunchKernelGGL(k_gwb_twiddle_sym<10>, g, dim3(64), 0, pta_stream(stream), sqrtC, Nf, npts, i0, inv_dt, Tsym, rot);
+  else
+    hipLaunchKernelGGL(k_gwb_twiddle_sym<7>, g, dim3(64), 0, pta_stream(stream), sqrtC, Nf, npts, i0, inv_dt, Tsym, rot);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot,
+                                int npts, double *G0, int64_t ldg, void *stream) {
+  PTA_REQUIRE(Tsym && rot && G0, PTA_E_ARG, "pta_gwb_idft_rng: NULL argument");
+  PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && Nf >= 3 && npts > 0 && ldg >= npts, PTA_E_ARG,
               "pta_gwb_idft_rng: R=%d P=%d Nf=%d npts=%d", R, P, Nf, npts);
   int64_t M64 = (int64_t)R * P;
   PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_idft_rng: R*P too large");
-  int M = (int)M64;
-  size_t shmem = 2 * IR_BUF * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
-    PTA_HIP(hipFuncSetAttribute((const void *)k_gwb_idft_rng, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    attr_set = true;
+  const int M = (int)M64;
+  const int nt = sym_nt();
+  const int half = (npts + 1) >> 1;
+  const int nchunk = (half + nt * 16 - 1) / (nt * 16);
+  const size_t shmem = 2 * (size_t)sym_slab_pad(nt) * sizeof(double);
+  dim3 g(pta_cdiv(M, 64), nchunk);
+  if (nt == 19) {
+    auto kern = k_gwb_idft_sym_rng<19, 1>;
+    PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
+  } else if (nt == 10) {
+    auto kern = k_gwb_idft_sym_rng<10, 2>;
+    PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
+  } else {
+    auto kern = k_gwb_idft_sym_rng<7, 2>;
+    PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
   }
-  for (int col0 = 0; col0 < npts; col0 += IR_LD) {
-    hipLaunchKernelGGL(k_gwb_idft_rng, dim3(pta_cdiv(M, 64)), dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, T, ldt,
-                       npts, col0, G0, ldg);
-    PTA_LAUNCH_CHECK();
-  }
+  PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
 

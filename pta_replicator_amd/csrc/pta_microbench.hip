@@ -65,6 +65,8 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result
   hipDeviceProp_t prop;
   PTA_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount;
+  // kinds 0/1/4: `bytes` in 1..32 selects the number of 256-thread blocks per CU (= waves per SIMD); default 8
+  const int bpc = ((kind == 0 || kind == 1 || kind == 4) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
   hipEvent_t e0, e1;
   PTA_HIP(hipEventCreate(&e0));
   PTA_HIP(hipEventCreate(&e1));
@@ -81,12 +83,12 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result
     for (int rep = 0; rep < reps; ++rep) {
       switch (kind) {
         case 0:
-          hipLaunchKernelGGL(k_mb_mfma, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
-          work = (double)cus * 8 * 4 * iters * 8.0 * 2048.0 * reps;  // waves * mfma * flop
+          hipLaunchKernelGGL(k_mb_mfma, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 4 * iters * 8.0 * 2048.0 * reps;  // waves * mfma * flop
           break;
         case 1:
-          hipLaunchKernelGGL(k_mb_fma, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
-          work = (double)cus * 8 * 256 * iters * 16.0 * 2.0 * reps;
+          hipLaunchKernelGGL(k_mb_fma, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 256 * iters * 16.0 * 2.0 * reps;
           break;
         case 2:
           hipLaunchKernelGGL(k_mb_write, dim3(cus * 8), dim3(256), 0, 0, (double2 *)buf, nbytes / 16);
@@ -97,8 +99,8 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result
           work = 2.0 * (double)nbytes * reps;
           break;
         case 4:
-          hipLaunchKernelGGL(k_mb_rng, dim3(cus * 8), dim3(256), 0, 0, buf, iters);
-          work = (double)cus * 8 * 256 * iters * 2.0 * reps;  // normals
+          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 256 * iters * 2.0 * reps;  // normals
           break;
         default:
           pta_set_error("pta_microbench: unknown kind %d", kind);

@@ -220,6 +220,12 @@ class ReplicaEngine:
             self.d_T = dv.empty((2 * (Nf - 2), self.ldt))
             sqrtC = dv.f64(self.C ** 0.5)
             _lib.call("pta_gwb_twiddle", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_T), self.ldt, s)
+            # throughput-mode layout of the same twiddles: half window, slab-major, plus the per-bin rotation
+            nrot = ctypes.c_int64(0)
+            nsym = _lib.lib.pta_gwb_twiddle_sym_size(Nf, npts, ctypes.byref(nrot))
+            self.d_Tsym, self.d_rot = dv.empty((nsym,)), dv.empty((nrot.value,))
+            _lib.call("pta_gwb_twiddle_sym", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_Tsym),
+                      dv.ptr(self.d_rot), s)
             self.d_ut = dv.f64(grid["ut"])
             self.d_jlo = dv.empty((N,), dtype=torch.int32)
             _lib.call("pta_gwb_bracket", dv.ptr(self.d_ut), npts, dv.ptr(self.d_toa_s), N, dv.ptr(self.d_jlo), s)
@@ -301,7 +307,7 @@ class ReplicaEngine:
             pl.rn_coef = ws["coef"].data_ptr()
         if pl.gw_npts:
             npts = pl.gw_npts
-            _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_T), self.ldt, npts,
+            _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_Tsym), dv.ptr(self.d_rot), npts,
                       dv.ptr(ws["G0"]), npts, s)
             _lib.call("pta_gwb_mix", dv.ptr(self.d_M), self.P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s)
             pl.gw_G = ws["G"].data_ptr()

@@ -14,7 +14,7 @@ def declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|const char \*)\s*\*?\s*(pta_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int64_t|int|const char \*)\s*\*?\s*(pta_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
     return out
