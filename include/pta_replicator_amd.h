@@ -174,14 +174,21 @@ int pta_cgw(const double *mjd, int N, const double *par_host, double *out, int a
 /* One pass that writes R whole-array realisations: out[r, i] = RN + GWB + WN + ECORR + det,
  * every deviate generated on chip (throughput mode).  All arrays are device pointers; any
  * signal whose pointer is NULL is skipped.                                                  */
+#define PTA_ENGINE_TILE 256     /* TOAs per workgroup tile; a tile never straddles two pulsars */
+#define PTA_ENGINE_EPMAX 132    /* ECORR pairs (= 264 epochs) a tile can stage through LDS per realisation */
 typedef struct {
   int32_t n_toa;              /* sum of N_a */
   int32_t n_psr;              /* P */
   int32_t rn_k;               /* 2*components (0 = no red noise) */
   int32_t gw_npts;            /* 0 = no GWB */
   int32_t tnequad;
-  int32_t reserved;
-  const int32_t *psr_of_toa;  /* [n_toa] pulsar index of each TOA (TOAs of a pulsar are contiguous) */
+  int32_t n_tiles;
+  const int32_t *tile_psr;    /* [n_tiles] pulsar of the tile */
+  const int32_t *tile_start;  /* [n_tiles] index (in the concatenated TOA axis) of the tile's first TOA */
+  const int32_t *tile_count;  /* [n_tiles] TOAs in the tile, <= PTA_ENGINE_TILE */
+  const int32_t *tile_ep0;    /* [n_tiles] first ECORR pair index (epoch >> 1) the tile touches */
+  const int32_t *tile_epn;    /* [n_tiles] number of pairs it touches; 0 = more than PTA_ENGINE_EPMAX (epochs not
+                                 contiguous along the TOA axis): deviates are then evaluated per TOA */
   const int32_t *idx_in_psr;  /* [n_toa] index of the TOA inside its pulsar (WN pair index) */
   const double *Ft;           /* [rn_k x ldf] design matrix rows for the concatenated TOAs */
   int64_t ldf;
@@ -199,6 +206,9 @@ typedef struct {
 
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
 int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, void *stream);
+
+/* tuning knob: minimum waves per SIMD the fused kernel is compiled for (4, 6 [default] or 8) */
+int pta_set_synth_variant(int min_waves_per_simd);
 
 int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
                      void *stream);

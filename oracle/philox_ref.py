@@ -49,23 +49,24 @@ def _blocks(seed, realisation, stream, npairs, pair0=0):
 
 
 def uniform_pairs(seed, realisation, stream, npairs, pair0=0):
+    """u1 in (0,1], u2 in [0,1): 52 random bits dropped into the mantissa of a double in [1,2)."""
     v = _blocks(seed, realisation, stream, npairs, pair0).astype(np.uint64)
-    a = ((v[:, 0] << np.uint64(32)) | v[:, 1]) >> np.uint64(11)
-    b = ((v[:, 2] << np.uint64(32)) | v[:, 3]) >> np.uint64(11)
-    u1 = (a.astype(np.float64) + 1.0) * 2.0 ** -53
-    u2 = b.astype(np.float64) * 2.0 ** -53
+    one = np.uint64(0x3FF0000000000000)
+    a = (((v[:, 0] << np.uint64(32)) | v[:, 1]) >> np.uint64(12)) | one
+    b = (((v[:, 2] << np.uint64(32)) | v[:, 3]) >> np.uint64(12)) | one
+    u1 = 2.0 - a.view(np.float64)
+    u2 = b.view(np.float64) - 1.0
     return u1, u2
 
 
 def normal_pairs(seed, realisation, stream, npairs, pair0=0):
-    """(z0[npairs], z1[npairs]): Box-Muller of the two 53-bit uniforms of each Philox block."""
+    """(z0[npairs], z1[npairs]): Box-Muller of the two uniforms of each Philox block.  The device evaluates
+    -2 ln u and sin/cos(2 pi u) with its own < 1 ulp kernels (pta_rng.h); libm here agrees to ~1e-16."""
     u1, u2 = uniform_pairs(seed, realisation, stream, npairs, pair0)
-    rad = np.sqrt(-2.0 * np.log(u1))
-    # exact quadrant reduction, like sincospi on the device
-    x = 2.0 * u2
-    q = np.floor(2.0 * x + 0.5)
-    rem = x - 0.5 * q
-    sr, cr = np.sin(np.pi * rem), np.cos(np.pi * rem)
+    rad = np.sqrt(np.maximum(-2.0 * np.log(u1), 1e-300))
+    q = np.rint(4.0 * u2)                  # exact reduction to the nearest quarter turn, like the device
+    x = 6.283185307179586 * (u2 - 0.25 * q)
+    sr, cr = np.sin(x), np.cos(x)
     qi = q.astype(np.int64) & 3
     s = np.choose(qi, [sr, cr, -sr, -cr])
     c = np.choose(qi, [cr, -sr, -cr, sr])

@@ -33,8 +33,9 @@ class EnginePlan(ctypes.Structure):
     """pta_engine_plan (include/pta_replicator_amd.h)."""
     _fields_ = [
         ("n_toa", c_int32), ("n_psr", c_int32), ("rn_k", c_int32), ("gw_npts", c_int32), ("tnequad", c_int32),
-        ("reserved", c_int32),
-        ("psr_of_toa", _P), ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
+        ("n_tiles", c_int32),
+        ("tile_psr", _P), ("tile_start", _P), ("tile_count", _P), ("tile_ep0", _P), ("tile_epn", _P),
+        ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
         ("gw_ut", _P), ("toa_s", _P), ("gw_jlo", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
         ("ecorr_toa", _P), ("det", _P),
     ]
@@ -67,6 +68,7 @@ _SIGNATURES = {
     "pta_gwb_interp": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_double, _P, c_int64, c_int, _P]),
     "pta_cgw": (c_int, [_P, c_int, _P, _P, c_int, _P]),
     "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, _P]),
+    "pta_set_synth_variant": (c_int, [c_int]),
     "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
@@ -75,6 +77,9 @@ _SIGNATURES = {
     "pta_microbench": (c_int, [c_int, c_int64, c_int, POINTER(c_double)]),
     "pta_selftest_mfma_f64": (c_int, [POINTER(c_double)]),
 }
+
+ENGINE_TILE = 256   # PTA_ENGINE_TILE
+ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
 
 EXPORTS = tuple(_SIGNATURES)
 

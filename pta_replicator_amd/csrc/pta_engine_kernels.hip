@@ -34,28 +34,59 @@ extern "C" int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int 
   return PTA_OK;
 }
 
-#define ENG_RB 4  // realisations per thread: amortises the realisation-independent loads (Ft row, noise vectors)
+// One workgroup = one tile of <= 256 consecutive TOAs of ONE pulsar x ENG_RB realisations; one thread = one TOA.
+//  * the pulsar and the realisations are workgroup-uniform, so the 60 red-noise coefficients and the GWB row
+//    base come through the scalar unit (s_load) and feed v_fma_f64 directly - no per-lane gathers;
+//  * the per-TOA vectors (Ft column, noise levels, bracket) are read once and reused for ENG_RB realisations;
+//  * ECORR deviates are shared by the TOAs of an epoch, and Box-Muller yields them in pairs: the tile draws the
+//    contiguous pair range its epochs cover once into LDS instead of one pair per TOA (halves that RNG work).
+#define ENG_RB 8
 
-__global__ __launch_bounds__(256) void k_engine_synth(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
-                                                      double *__restrict__ out, int64_t ld_out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int rb = blockIdx.y * ENG_RB;
-  if (i >= pl.n_toa) return;
-  const int a = pl.psr_of_toa[i];
+template <int MINW>
+__global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
+                                                                  double *__restrict__ out, int64_t ld_out) {
+  __shared__ double zec[ENG_RB][2 * PTA_ENGINE_EPMAX];
+  // realisation groups are the FAST grid axis: the workgroups that share a tile's Ft columns / noise vectors run
+  // back to back and hit L2 (with tiles fastest every sweep re-read the whole 163 MB design matrix from HBM:
+  // rocprofv3 FETCH_SIZE 11.6 GB per launch against 2.6 GB written)
+  const int tile = blockIdx.y;
+  const int rb = blockIdx.x * ENG_RB;
+  const int a = pl.tile_psr[tile];
+  const int start = pl.tile_start[tile];
+  const int count = pl.tile_count[tile];
+  const int t = threadIdx.x;
   const int P = pl.n_psr;
+  const bool has_ec = pl.ecorr_toa != nullptr;
+  const int epn = has_ec ? pl.tile_epn[tile] : 0;
+  const int ep0 = has_ec ? pl.tile_ep0[tile] : 0;
+  if (epn > 0) {
+    const uint32_t strm = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
+    for (int idx = t; idx < epn * ENG_RB; idx += PTA_ENGINE_TILE) {
+      int q = idx / epn, p = idx - q * epn;
+      double z0, z1;
+      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)(ep0 + p), z0, z1);
+      zec[q][2 * p] = z0;
+      zec[q][2 * p + 1] = z1;
+    }
+    __syncthreads();
+  }
+  if (t >= count) return;
+  const int i = start + t;
   double v[ENG_RB];
-  const double det = pl.det ? pl.det[i] : 0.0;
 #pragma unroll
   for (int q = 0; q < ENG_RB; ++q) v[q] = 0.0;
 
-  if (pl.rn_k > 0) {  // red noise: dt = F @ y (red_noise.py:128)
+  if (pl.rn_k > 0) {  // red noise: dt = F @ y (red_noise.py:128); coefficients are wave-uniform
     const int K = pl.rn_k;
+    const double *__restrict__ Fcol = pl.Ft + i;
+    const double *__restrict__ cf = pl.rn_coef + ((int64_t)rb * P + a) * K;
+    const int64_t rstride = (int64_t)P * K;
     for (int c = 0; c < K; ++c) {
-      double fv = pl.Ft[(int64_t)c * pl.ldf + i];
+      double fv = Fcol[(int64_t)c * pl.ldf];
 #pragma unroll
       for (int q = 0; q < ENG_RB; ++q) {
-        int r = min(rb + q, R - 1);
-        v[q] = fma(fv, pl.rn_coef[((int64_t)r * P + a) * K + c], v[q]);
+        int qq = (rb + q < R) ? q : 0;
+        v[q] = fma(fv, cf[qq * rstride + c], v[q]);
       }
     }
   }
@@ -63,10 +94,12 @@ __global__ __launch_bounds__(256) void k_engine_synth(pta_engine_plan pl, uint64
     const int j = pl.gw_jlo[i];
     const double x = pl.toa_s[i];
     const double x0 = pl.gw_ut[j], dx = pl.gw_ut[j + 1] - x0;
+    const double *__restrict__ gbase = pl.gw_G + ((int64_t)rb * P + a) * pl.gw_npts;
+    const int64_t rstride = (int64_t)P * pl.gw_npts;
 #pragma unroll
     for (int q = 0; q < ENG_RB; ++q) {
-      int r = min(rb + q, R - 1);
-      const double *g = pl.gw_G + ((int64_t)r * P + a) * pl.gw_npts;
+      int qq = (rb + q < R) ? q : 0;
+      const double *g = gbase + qq * rstride;
       double slope = (g[j + 1] - g[j]) / dx;
       v[q] = v[q] + (slope * (x - x0) + g[j]);
     }
@@ -82,18 +115,29 @@ __global__ __launch_bounds__(256) void k_engine_synth(pta_engine_plan pl, uint64
       v[q] = v[q] + (wa * z1 + wb * z2);
     }
   }
-  if (pl.ecorr_toa) {  // ECORR: ecorr[e(i)] z[e(i)] (white_noise.py:182)
+  if (has_ec) {  // ECORR: ecorr[e(i)] z[e(i)] (white_noise.py:182)
     const double ec = pl.ecorr_toa[i];
-    if (ec != 0.0) {
-      const uint32_t strm = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
-      const uint32_t e = (uint32_t)pl.epoch_of[i];
+    const int e = pl.epoch_of[i];
+    if (epn > 0) {
+      const int o = e - 2 * ep0;
 #pragma unroll
-      for (int q = 0; q < ENG_RB; ++q) v[q] = v[q] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + q), strm, e);
+      for (int q = 0; q < ENG_RB; ++q) v[q] = v[q] + ec * zec[q][o];
+    } else if (ec != 0.0) {
+      const uint32_t strm = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
+#pragma unroll
+      for (int q = 0; q < ENG_RB; ++q) v[q] = v[q] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)e);
     }
   }
+  const double det = pl.det ? pl.det[i] : 0.0;
 #pragma unroll
   for (int q = 0; q < ENG_RB; ++q)
     if (rb + q < R) out[(int64_t)(rb + q) * ld_out + i] = v[q] + det;
+}
+
+static int g_synth_minw = 6;
+extern "C" int pta_set_synth_variant(int minw) {
+  g_synth_minw = minw;
+  return PTA_OK;
 }
 
 extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
@@ -102,15 +146,23 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   const pta_engine_plan &p = *plan_host;
   PTA_REQUIRE(p.n_toa > 0 && p.n_psr > 0 && R > 0 && ld_out >= p.n_toa, PTA_E_ARG, "pta_engine_synth: n_toa=%d n_psr=%d R=%d", p.n_toa,
               p.n_psr, R);
-  PTA_REQUIRE(p.psr_of_toa && p.idx_in_psr, PTA_E_ARG, "pta_engine_synth: psr_of_toa / idx_in_psr missing");
+  PTA_REQUIRE(p.n_tiles > 0 && p.tile_psr && p.tile_start && p.tile_count && p.tile_ep0 && p.tile_epn && p.idx_in_psr, PTA_E_ARG,
+              "pta_engine_synth: tile table / idx_in_psr missing");
   PTA_REQUIRE(p.rn_k == 0 || (p.Ft && p.rn_coef && p.ldf >= p.n_toa), PTA_E_ARG, "pta_engine_synth: red-noise inputs missing");
   PTA_REQUIRE(p.gw_npts == 0 || (p.gw_G && p.gw_ut && p.gw_jlo && p.toa_s && p.gw_npts >= 2), PTA_E_ARG,
               "pta_engine_synth: GWB inputs missing");
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
-  PTA_REQUIRE(pta_cdiv(R, ENG_RB) <= 65535u, PTA_E_ARG, "pta_engine_synth: R=%d too large for one launch", R);
-  hipLaunchKernelGGL(k_engine_synth, dim3(pta_cdiv(p.n_toa, 256), pta_cdiv(R, ENG_RB)), dim3(256), 0, pta_stream(stream), p, seed, r0, R,
-                     out, ld_out);
+  PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed one launch", p.n_tiles);
+  dim3 g(pta_cdiv(R, ENG_RB), p.n_tiles), b(PTA_ENGINE_TILE);
+  // register budget per lane (waves per SIMD the compiler must allow): the kernel alternates long Box-Muller chains
+  // with a load-fed FMA loop, so occupancy matters more than keeping all eight chains' temporaries in registers
+  if (g_synth_minw >= 8)
+    hipLaunchKernelGGL(k_engine_synth<8>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
+  else if (g_synth_minw >= 6)
+    hipLaunchKernelGGL(k_engine_synth<6>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
+  else
+    hipLaunchKernelGGL(k_engine_synth<4>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

@@ -71,37 +71,113 @@ PTA_HD pta_u32x4 pta_philox_draw(uint64_t seed, uint64_t realisation, uint32_t s
   return pta_philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-// two 53-bit uniforms from one Philox block: u1 in (0,1], u2 in [0,1)
-PTA_HD void pta_uniform_pair(pta_u32x4 v, double &u1, double &u2) {
-  uint64_t a = (((uint64_t)v.x << 32) | v.y) >> 11;
-  uint64_t b = (((uint64_t)v.z << 32) | v.w) >> 11;
-  u1 = ((double)a + 1.0) * 0x1.0p-53;
-  u2 = (double)b * 0x1.0p-53;
+// Two 52-bit uniforms from one Philox block: u1 in (0,1], u2 in [0,1).  The 52 random bits are dropped
+// straight into the mantissa of a double in [1,2) (three integer ops + one exact subtraction per uniform).
+PTA_HD double pta_bits_to_double(uint64_t b) {
+  double d;
+  __builtin_memcpy(&d, &b, sizeof(d));
+  return d;
+}
+PTA_HD uint64_t pta_double_to_bits(double d) {
+  uint64_t b;
+  __builtin_memcpy(&b, &d, sizeof(b));
+  return b;
 }
 
-PTA_HD void pta_sincos_2pi(double u, double &s, double &c) {
+PTA_HD void pta_uniform_pair(pta_u32x4 v, double &u1, double &u2) {
+  uint64_t a = ((((uint64_t)v.x << 32) | v.y) >> 12) | 0x3FF0000000000000ull;
+  uint64_t b = ((((uint64_t)v.z << 32) | v.w) >> 12) | 0x3FF0000000000000ull;
+  u1 = 2.0 - pta_bits_to_double(a);
+  u2 = pta_bits_to_double(b) - 1.0;
+}
+
+// x/y and sqrt(x) without the IEEE division / square-root expansions: those lean on VCC (v_div_scale ->
+// v_div_fmas) and on long fix-up tails, which serialises the eight independent Box-Muller chains a thread of the
+// fused kernel keeps in flight.  Hardware reciprocal / reciprocal-sqrt seeds (~2^-23) + two Newton steps + one
+// residual correction: < 1 ulp for the well-scaled arguments used here.  The host twins are the plain operators.
+PTA_HD double pta_div(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  sincospi(2.0 * u, &s, &c);
+  double r = __builtin_amdgcn_rcp(y);
+  r = fma(fma(-y, r, 1.0), r, r);
+  r = fma(fma(-y, r, 1.0), r, r);
+  double q = x * r;
+  return fma(fma(-y, q, x), r, q);
 #else
-  // host twin (tests only): exact quadrant reduction, then libm
-  double x = 2.0 * u;            // [0, 2)
-  double q = floor(2.0 * x + 0.5);  // nearest multiple of 1/2
-  double rem = x - 0.5 * q;      // [-1/4, 1/4]
-  double sr = sin(M_PI * rem), cr = cos(M_PI * rem);
-  switch (((int)q) & 3) {
-    case 0: s = sr; c = cr; break;
-    case 1: s = cr; c = -sr; break;
-    case 2: s = -sr; c = -cr; break;
-    default: s = -cr; c = sr; break;
-  }
+  return x / y;
 #endif
+}
+PTA_HD double pta_sqrt_pos(double x) {  // x >= 0; exact zero is nudged to 1e-300 (sqrt -> 1e-150) to keep rsq finite
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = fmax(x, 1e-300);
+  double r = __builtin_amdgcn_rsq(x);
+  double g = x * r, h = 0.5 * r;
+  double d = fma(-h, g, 0.5);
+  g = fma(g, d, g);
+  h = fma(h, d, h);
+  d = fma(-h, g, 0.5);
+  g = fma(g, d, g);
+  h = fma(h, d, h);
+  return fma(fma(-g, g, x), h, g);
+#else
+  return sqrt(fmax(x, 1e-300));
+#endif
+}
+
+// -2 ln(u) for u in (0,1].  Classic argument reduction u = 2^e m, m in [sqrt(1/2), sqrt(2)), then
+// ln(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))), s = f/(2+f), with the degree-14 minimax R of Sun's fdlibm
+// (public domain, e_log.c; < 1 ulp).  About a third of the instructions of the generic library log(),
+// which matters because Gaussian generation is the VALU-bound part of the whole pipeline.
+PTA_HD double pta_neg2log(double u) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  uint64_t b = pta_double_to_bits(u);
+  int e = (int)(b >> 52) - 1023;
+  double m = pta_bits_to_double((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);  // [1,2)
+  if (m > 1.4142135623730951) {
+    m *= 0.5;
+    e += 1;
+  }
+  double f = m - 1.0;
+  double s = pta_div(f, 2.0 + f);
+  double z = s * s, w = z * z;
+  double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+  double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  double dk = (double)e;
+  double lnu = dk * ln2_hi - ((hfsq - fma(s, hfsq + R, dk * ln2_lo)) - f);
+  return -2.0 * lnu;
+}
+
+// sin(2 pi u), cos(2 pi u) for u in [0,1): exact reduction to the nearest quarter turn, then the fdlibm
+// kernels (k_sin.c / k_cos.c, |x| <= pi/4, < 1 ulp) and a quadrant rotation.
+PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double q = rint(4.0 * u);        // 0..4
+  double r = u - 0.25 * q;         // [-1/8, 1/8], exact
+  double x = 6.283185307179586 * r;
+  double z = x * x;
+  double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+  double s = fma(x * z, ps, x);
+  double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  double c = 1.0 - (0.5 * z - z * pc);
+  int k = (int)q & 3;
+  double s1 = (k & 1) ? c : s;
+  double c1 = (k & 1) ? s : c;
+  sn = (k == 2 || k == 3) ? -s1 : s1;   // k: 0 (s,c) 1 (c,-s) 2 (-s,-c) 3 (-c,s)
+  cs = (k == 1 || k == 2) ? -c1 : c1;
 }
 
 // Box-Muller: (z0, z1) iid N(0,1)
 PTA_HD void pta_normal_pair(uint64_t seed, uint64_t realisation, uint32_t stream, uint32_t pair, double &z0, double &z1) {
   double u1, u2, s, c;
   pta_uniform_pair(pta_philox_draw(seed, realisation, stream, pair), u1, u2);
-  double rad = sqrt(-2.0 * log(u1));
+  double rad = pta_sqrt_pos(pta_neg2log(u1));
   pta_sincos_2pi(u2, s, c);
   z0 = rad * c;
   z1 = rad * s;

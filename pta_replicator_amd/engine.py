@@ -105,7 +105,7 @@ class ReplicaEngine:
         self.plan = _lib.EnginePlan()
         pl = self.plan
         pl.n_toa, pl.n_psr = N, P
-        pl.psr_of_toa, pl.idx_in_psr = self.d_psr_of.data_ptr(), self.d_idx_in.data_ptr()
+        pl.idx_in_psr = self.d_idx_in.data_ptr()
         pl.toa_s = self.d_toa_s.data_ptr()
 
         # ---- red noise: Ft [K, N] over the concatenated TOAs and amp = sqrt(prior) [P, K]
@@ -203,6 +203,23 @@ class ReplicaEngine:
                 ec_all[sl] = vec[epoch_of]
             self.d_epoch_of, self.d_ecorr_toa = dv.i32(ep_all), dv.f64(ec_all)
             pl.epoch_of, pl.ecorr_toa = self.d_epoch_of.data_ptr(), self.d_ecorr_toa.data_ptr()
+
+        # ---- workgroup tiles: <= ENGINE_TILE consecutive TOAs of ONE pulsar, plus the ECORR pair range they touch
+        T = _lib.ENGINE_TILE
+        t_psr, t_start, t_count, t_ep0, t_epn = [], [], [], [], []
+        for a in range(P):
+            for s0 in range(0, int(self.counts[a]), T):
+                cnt = min(T, int(self.counts[a]) - s0)
+                t_psr.append(a); t_start.append(int(self.off[a]) + s0); t_count.append(cnt)
+                if self._ec is not None:
+                    e = self.epoch_of[a][s0:s0 + cnt]
+                    p0, p1 = int(e.min()) >> 1, int(e.max()) >> 1
+                    t_ep0.append(p0); t_epn.append(p1 - p0 + 1 if p1 - p0 + 1 <= _lib.ENGINE_EPMAX else 0)
+                else:
+                    t_ep0.append(0); t_epn.append(0)
+        self.d_tiles = [dv.i32(x) for x in (t_psr, t_start, t_count, t_ep0, t_epn)]
+        pl.n_tiles = len(t_psr)
+        pl.tile_psr, pl.tile_start, pl.tile_count, pl.tile_ep0, pl.tile_epn = [x.data_ptr() for x in self.d_tiles]
 
         # ---- GWB: grid, ORF, Cholesky, spectrum, twiddles, brackets
         pl.gw_npts = 0

@@ -31,18 +31,12 @@ def timed(fn, reps=5):
 
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 960
-for variant in (0, 1, 2):
-    _lib.call("pta_set_idft_variant", variant)
-    eng, psrs, noise = build_engine(68, 5000, seed=1)
-    s = dv.stream_ptr()
-    ws = eng.workspace(R)
-    P, Nf, npts = eng.P, eng.grid["Nf"], eng.plan.gw_npts
-    t = timed(lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts, s))
-    fl = 2.0 * R * P * 2 * (Nf - 2) * 300
-    print(json.dumps({"idft_variant": variant, "R": R, "ms": round(t, 3), "us_per_real": round(t * 1e3 / R, 3), "exec_tflops": round(fl / t / 1e9, 2)}))
+_lib.call("pta_set_idft_variant", 1)
+eng, psrs, noise = build_engine(68, 5000, seed=1)
+s = dv.stream_ptr()
 outb = dv.empty((R, eng.n_toa))
 eng.generate(R, out=outb)
-t = timed(lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(outb), outb.stride(0), s))
-print(json.dumps({"synth_ms": round(t, 3), "us_per_real": round(t * 1e3 / R, 3), "GBps": round(8.0 * eng.n_toa * R / t / 1e6, 1)}))
-t = timed(lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s))
-print(json.dumps({"mix_ms": round(t, 3)}))
+for w in (4, 6, 8):
+    _lib.call("pta_set_synth_variant", w)
+    t = timed(lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(outb), outb.stride(0), s))
+    print(json.dumps({"synth_minw": w, "synth_ms": round(t, 3), "us_per_real": round(t * 1e3 / R, 3), "GBps": round(8.0 * eng.n_toa * R / t / 1e6, 1)}))
