@@ -122,6 +122,53 @@ def cpu_baseline(psrs, noise, repeats=1):
             "host_cpus": os.cpu_count()}
 
 
+def td_mode_numbers(N, B, R):
+    """Secondary metric of BASELINE.json: the dense time-domain path (no counterpart in the reference) - covariance
+    assembly GB/s, blocked fp64 Cholesky TFLOP/s (MFMA trailing update) and L.Z TFLOP/s for B pulsars of N TOAs."""
+    import ctypes
+    import torch
+    from pta_replicator_amd import _lib, device as dv
+    s = dv.stream_ptr()
+    nm = 30
+    rng = np.random.default_rng(5)
+    t = np.sort(rng.uniform(53000, 58478, N)) * 86400.0
+    Tspan = t.max() - t.min()
+    f = np.arange(1, nm + 1) / Tspan
+    freqs = np.repeat(f, 2)
+    phi = (10 ** -14.0) ** 2 * (freqs * 365.25 * 86400) ** (-3.0) / (12 * np.pi ** 2 * Tspan) * (365.25 * 86400) ** 3
+    from pta_replicator_amd.white_noise import epoch_map
+    epoch_of, first = epoch_map(t / 86400.0, 0.1)
+    t_d, f_d, phi_d = dv.f64(t), dv.f64(f), dv.f64(phi)
+    sig_d, ep_d, ec_d = dv.f64(np.full(N, 0.25e-12)), dv.i32(epoch_of), dv.f64(np.full(N, 4e-14))
+    Ft = dv.empty((2 * nm, N))
+    _lib.call("pta_rn_basis", dv.ptr(t_d), N, 0.0, dv.ptr(f_d), None, nm, 0, dv.ptr(Ft), N, s)
+    C = dv.zeros((B, N, N))
+    info = dv.zeros((B,), dtype=torch.int32)
+
+    def assemble():
+        for b in range(B):
+            _lib.call("pta_td_cov_assemble", dv.ptr(Ft), N, N, 2 * nm, dv.ptr(phi_d), dv.ptr(sig_d), dv.ptr(ep_d), dv.ptr(ec_d),
+                      ctypes.c_void_p(C.data_ptr() + 8 * b * N * N), N, s)
+
+    def wall(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    assemble()
+    ta = wall(assemble)
+    tp = wall(lambda: _lib.call("pta_potrf_batched", dv.ptr(C), N, B, dv.ptr(info), s))
+    ok = int(info.abs().sum().item()) == 0
+    z, out = dv.empty((R, N)), dv.empty((R, N))
+    _lib.call("pta_rng_fill_normal", 1, 0, R, (5 << 24), N // 2, 1, dv.ptr(z), None, N, s)
+    _lib.call("pta_td_trmm", dv.ptr(C), N, N, dv.ptr(z), N, R, dv.ptr(out), N, 0, s)
+    tt = wall(lambda: _lib.call("pta_td_trmm", dv.ptr(C), N, N, dv.ptr(z), N, R, dv.ptr(out), N, 0, s))
+    potrf_tf = N ** 3 / 3.0 * B / tp / 1e12
+    return {"n_toa": N, "n_psr": B, "positive_definite": ok,
+            "cov_assemble_GBps": 8.0 * N * (N + 64) / 2 * B / ta / 1e9,
+            "potrf_TFLOPs": potrf_tf, "potrf_frac_of_fp64_mfma_peak": potrf_tf / FP64_MFMA_PEAK_TFLOPS, "potrf_ms": tp * 1e3,
+            "trmm_TFLOPs_executed": 2.0 * N * N * R / tt / 1e12, "trmm_realisations_per_s_per_pulsar": R / tt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +178,7 @@ def main():
     ap.add_argument("--psr", type=int, default=68)
     ap.add_argument("--toa", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-td", action="store_true", help="skip the TD-mode (dense covariance / Cholesky / L.z) side measurement")
     ap.add_argument("--gather", action="store_true", help="also time the gather of the residual arrays to rank 0")
     args = ap.parse_args()
 
@@ -239,6 +287,13 @@ def main():
     except Exception as e:  # pragma: no cover
         micro["error"] = str(e)
 
+    td = None
+    if not args.no_td:
+        try:
+            td = td_mode_numbers(args.toa, 8, 512)
+        except Exception as e:  # pragma: no cover
+            td = {"error": str(e)}
+
     line = {
         "metric": "realizations/sec, 68 psr x 5000 TOAs GWB+RN+WN", "value": world * R * K / elapsed, "unit": "realizations/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -248,6 +303,8 @@ def main():
                    "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
         "roofline": roof, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
     }
+    if td is not None:
+        line["td_mode"] = td
     if gather_ms is not None:
         line["gather_ms"] = gather_ms
     if world == 1 and not args.no_cpu_baseline:

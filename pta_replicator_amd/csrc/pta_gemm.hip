@@ -101,6 +101,110 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
       }
 }
 
+// Large-operand variant: 128x128 C tile per workgroup (4 waves as 2x2, each 64x64 = 4x4 MFMA tiles, 128
+// accumulator VGPRs), K slabs of 16 double-buffered in LDS with the next slab prefetched into registers under
+// the 64 MFMAs of the current one: one barrier per slab, 8 fragment reads per 16 MFMAs.  Used by the Cholesky
+// trailing update and TD mode's L.Z, where the operands are large enough to fill 128-wide tiles.
+#define HBM_T 128
+#define HLD 144  // == 16 (mod 32)
+
+template <bool BT>
+__global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, double alpha, const double *__restrict__ A,
+                                                          int64_t lda, int64_t ska, const double *__restrict__ B,
+                                                          int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
+                                                          int lower_only, int64_t sA, int64_t sB, int64_t sC) {
+  const int bm = blockIdx.y, bn = blockIdx.x;
+  if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) return;
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  __shared__ double As[2][GBK][HLD];
+  __shared__ double Bs[2][GBK][HLD];
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = bm * HBM_T, n0 = bn * HBM_T;
+  pta_f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  double ra[8], rb[8];
+  // A slab: 128 rows x 16 k, 8 consecutive k per thread.  B slab: [N x K] -> same pattern; [K x N] -> 16 k-rows x 8 n
+  const int a_row = t >> 1, a_kq = (t & 1) * 8;
+  const int b_kr = t >> 4, b_nq = (t & 15) * 8;
+  auto fetch = [&](int k0) {
+    int gm = m0 + a_row;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int gk = k0 + a_kq + j;
+      ra[j] = (gm < M && gk < K) ? A[(int64_t)gm * lda + (int64_t)gk * ska] : 0.0;
+    }
+    if (BT) {
+      int gn = n0 + a_row;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int gk = k0 + a_kq + j;
+        rb[j] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
+      }
+    } else {
+      int gk = k0 + b_kr;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int gn = n0 + b_nq + j;
+        rb[j] = (gk < K && gn < N) ? B[(int64_t)gk * ldb + gn] : 0.0;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) As[buf][a_kq + j][a_row] = ra[j];
+    if (BT) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Bs[buf][a_kq + j][a_row] = rb[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Bs[buf][b_kr][b_nq + j] = rb[j];
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int nslab = (K + GBK - 1) / GBK;
+  for (int sidx = 0; sidx < nslab; ++sidx) {
+    const int cur = sidx & 1;
+    const int knext = min(sidx + 1, nslab - 1) * GBK;  // the last slab harmlessly re-fetches itself
+    fetch(knext);
+#pragma unroll
+    for (int kk = 0; kk < GBK; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[cur][kk + (l >> 4)][wm * 64 + i * 16 + (l & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kk + (l >> 4)][wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+    }
+    stash(cur ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
+        int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
+        if (row < M && col < N && (!lower_only || col <= row)) {
+          int64_t o = (int64_t)row * ldc + col;
+          double v = alpha * acc[i][j][r];
+          C[o] = (beta == 0.0) ? v : v + beta * C[o];
+        }
+      }
+}
+
 // plain VALU kernel: one thread per C element.  Cross-check for the MFMA kernel and the fallback
 // for operand shapes too small to fill a tile.
 template <bool BT>
@@ -135,6 +239,13 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
       hipLaunchKernelGGL(k_dgemm_valu<true>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else
       hipLaunchKernelGGL(k_dgemm_valu<false>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+  } else if (algo == 1 && M >= 256 && N >= 128 && K >= 32) {  // large operands: 128x128 tiles
+    PTA_REQUIRE(pta_cdiv(M, HBM_T) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
+    dim3 g(pta_cdiv(N, HBM_T), pta_cdiv(M, HBM_T), batch);
+    if (transB)
+      hipLaunchKernelGGL(k_dgemm_mfma128<true>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    else
+      hipLaunchKernelGGL(k_dgemm_mfma128<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
   } else {
     PTA_REQUIRE(pta_cdiv(M, GBM) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
     dim3 g(pta_cdiv(N, GBN), pta_cdiv(M, GBM), batch);

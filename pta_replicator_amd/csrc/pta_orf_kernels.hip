@@ -75,10 +75,8 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, in
   __shared__ double djj;
   double *M = A + (int64_t)blockIdx.x * n * n;
   const int t = threadIdx.x;
-  for (int e = t; e < nb * nb; e += 256) {
-    int i = e / nb, c = e % nb;
-    S[i][c] = (c <= i) ? M[(int64_t)(k0 + i) * n + (k0 + c)] : 0.0;
-  }
+  for (int i = t >> 6; i < nb; i += 4)
+    for (int c = t & 63; c < nb; c += 64) S[i][c] = (c <= i) ? M[(int64_t)(k0 + i) * n + (k0 + c)] : 0.0;
   for (int j = 0; j < nb; ++j) {
     __syncthreads();
     if (t == 0) {
@@ -92,17 +90,15 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, in
     double inv = 1.0 / djj;
     for (int i = j + 1 + t; i < nb; i += 256) S[i][j] = S[i][j] * inv;
     __syncthreads();
-    int rem = nb - j - 1;
-    for (int e = t; e < rem * rem; e += 256) {
-      int i = j + 1 + e / rem, c = j + 1 + e % rem;
-      if (c <= i) S[i][c] = fma(-S[i][j], S[c][j], S[i][c]);
+    // rank-1 update of the trailing lower triangle; threads as a 16 x 16 grid striding the block (no divisions)
+    for (int i = j + 1 + (t >> 4); i < nb; i += 16) {
+      const double lij = S[i][j];
+      for (int c = j + 1 + (t & 15); c <= i; c += 16) S[i][c] = fma(-lij, S[c][j], S[i][c]);
     }
   }
   __syncthreads();
-  for (int e = t; e < nb * nb; e += 256) {
-    int i = e / nb, c = e % nb;
-    M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : 0.0;
-  }
+  for (int i = t >> 6; i < nb; i += 4)
+    for (int c = t & 63; c < nb; c += 64) M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int k0, int nb) {
@@ -112,30 +108,24 @@ __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int
   const int t = threadIdx.x;
   const int r0 = k0 + nb + blockIdx.x * CH_NB;
   const int rows = min(CH_NB, n - r0);
-  for (int e = t; e < nb * nb; e += 256) {
-    int i = e / nb, c = e % nb;
-    L[i][c] = M[(int64_t)(k0 + i) * n + (k0 + c)];
-  }
-  for (int e = t; e < rows * nb; e += 256) {
-    int i = e / nb, c = e % nb;
-    X[i][c] = M[(int64_t)(r0 + i) * n + (k0 + c)];
-  }
-  // X <- X L^{-T}: column sweep
+  for (int i = t >> 6; i < nb; i += 4)
+    for (int c = t & 63; c < nb; c += 64) L[i][c] = M[(int64_t)(k0 + i) * n + (k0 + c)];
+  for (int i = t >> 6; i < rows; i += 4)
+    for (int c = t & 63; c < nb; c += 64) X[i][c] = M[(int64_t)(r0 + i) * n + (k0 + c)];
+  // X <- X L^{-T}, column sweep.  Four threads per row: lane quartet q takes columns c = j+1+q, j+5+q, ...
+  const int row = t >> 2, q = t & 3;
   for (int j = 0; j < nb; ++j) {
     __syncthreads();
-    if (t < rows) X[t][j] = X[t][j] / L[j][j];
+    if (q == 0 && row < rows) X[row][j] = X[row][j] / L[j][j];
     __syncthreads();
-    int rem = nb - j - 1;
-    for (int e = t; e < rows * rem; e += 256) {
-      int i = e / rem, c = j + 1 + e % rem;
-      X[i][c] = fma(-X[i][j], L[c][j], X[i][c]);
+    if (row < rows) {
+      const double xj = X[row][j];
+      for (int c = j + 1 + q; c < nb; c += 4) X[row][c] = fma(-xj, L[c][j], X[row][c]);
     }
   }
   __syncthreads();
-  for (int e = t; e < rows * nb; e += 256) {
-    int i = e / nb, c = e % nb;
-    M[(int64_t)(r0 + i) * n + (k0 + c)] = X[i][c];
-  }
+  for (int i = t >> 6; i < rows; i += 4)
+    for (int c = t & 63; c < nb; c += 64) M[(int64_t)(r0 + i) * n + (k0 + c)] = X[i][c];
 }
 
 __global__ void k_zero_upper(double *__restrict__ A, int n) {
@@ -157,17 +147,34 @@ extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *s
   hipStream_t s = pta_stream(stream);
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   const int64_t nn = (int64_t)n * n;
-  for (int k0 = 0; k0 < n; k0 += CH_NB) {
-    int nb = (n - k0 < CH_NB) ? (n - k0) : CH_NB;
-    hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, s, A, n, k0, nb, info);
-    PTA_LAUNCH_CHECK();
-    int rows = n - k0 - nb;
-    if (rows > 0) {
-      hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, k0, nb);
+  // Two-level right-looking blocking.  A 64-wide panel step updates only the rest of its 256-wide outer panel;
+  // the bulk of the trailing matrix is updated once per outer panel with K = 256, which quarters the read+write
+  // traffic of the C tiles (at K = 64 the update is HBM-bound: 8 flop per byte of C).
+  const int NBO = 4 * CH_NB;
+  for (int k0 = 0; k0 < n; k0 += NBO) {
+    const int nbo = (n - k0 < NBO) ? (n - k0) : NBO;
+    const int pend = k0 + nbo;  // one past the outer panel's last column
+    for (int j0 = k0; j0 < pend; j0 += CH_NB) {
+      const int nb = (pend - j0 < CH_NB) ? (pend - j0) : CH_NB;
+      hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, s, A, n, j0, nb, info);
       PTA_LAUNCH_CHECK();
-      const double *L21 = A + (int64_t)(k0 + nb) * n + k0;
-      double *A22 = A + (int64_t)(k0 + nb) * n + (k0 + nb);
-      int rc = pta_dgemm_launch(1, rows, rows, nb, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
+      const int rows = n - j0 - nb;
+      if (rows <= 0) continue;
+      hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
+      PTA_LAUNCH_CHECK();
+      const int pcols = pend - (j0 + nb);  // columns of the outer panel still to be factored
+      if (pcols > 0) {
+        const double *L21 = A + (int64_t)(j0 + nb) * n + j0;
+        double *A22 = A + (int64_t)(j0 + nb) * n + (j0 + nb);
+        int rc = pta_dgemm_launch(1, rows, pcols, nb, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
+        if (rc != PTA_OK) return rc;
+      }
+    }
+    const int rows = n - pend;
+    if (rows > 0) {
+      const double *L21 = A + (int64_t)pend * n + k0;
+      double *A22 = A + (int64_t)pend * n + pend;
+      int rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
       if (rc != PTA_OK) return rc;
     }
   }

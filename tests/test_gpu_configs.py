@@ -1,0 +1,151 @@
+"""BASELINE.json configs 2, 4 and 5 at their full sizes on the MI355X (run with -m gpu): the CPU reference cannot
+produce these in test time, so they are checked through size-independent properties plus oracle spot checks."""
+import numpy as np
+import pytest
+
+from helpers import load, relrms
+from oracle import pta_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def _fused_equals_replay(eng, r):
+    out = eng.generate(1, r0=r).cpu().numpy()[0]
+    rep = eng.replay([eng.dump_draws(r)]).cpu().numpy()[0]
+    assert np.all(np.isfinite(out))
+    assert np.max(np.abs(out - rep)) < 1e-12 * np.sqrt(np.mean(rep ** 2))
+    return out
+
+
+def test_config2_test_partim_set_per_backend_noise_256_realisations():
+    """B1855+09 (real tim: 7758 unsorted TOAs, 4 backends) + B1937+21 / J1909-3744 synthesised at their par-file
+    NTOA (23023 / 35037), per-backend EFAC/EQUAD/ECORR (coarsegrain 1 s as in notebook cell 9) + per-pulsar RN."""
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    z = load("c2_b1855.npz")
+    backends = [str(b) for b in z["backends"]]
+    rng = np.random.default_rng(2)
+    psrs = []
+    mjd = z["mjd_hi"].astype(np.longdouble) + z["mjd_lo"].astype(np.longdouble)
+    flags = [{"f": backends[i]} for i in z["flag_index"]]
+    psrs.append(SimulatedPulsar(toas=ArrayTOAs(mjd, z["err_us"], flags), name="B1855+09", loc={"RAJ": 18.96, "DECJ": 9.72}))
+    for name, n, lo, hi, loc in (("B1937+21", 23023, 53420.0, 59070.0, {"RAJ": 19.66, "DECJ": 21.58}),
+                                 ("J1909-3744", 35037, 53292.0, 59070.0, {"RAJ": 19.16, "DECJ": -37.74})):
+        ep = np.sort(rng.uniform(lo, hi, n // 8 + 1))
+        m = (ep[:, None] + rng.uniform(0, 0.02, (len(ep), 8))).ravel()[:n]        # ~8 sub-band TOAs per epoch
+        fl = [{"f": backends[int(k)]} for k in rng.integers(0, 4, len(ep)).repeat(8)[:n]]
+        psrs.append(SimulatedPulsar(toas=ArrayTOAs(m, np.exp(rng.uniform(np.log(0.05), np.log(30.0), n)), fl), name=name, loc=loc))
+    for p in psrs:
+        make_ideal(p)
+    P = len(psrs)
+    eng = ReplicaEngine(psrs, seed=222)
+    eng.set_white_noise(efac=[z["efac"]] * P, log10_equad=[z["log10_equad"]] * P, flags=[list(z["efac_flags"])] * P)
+    eng.set_jitter(log10_ecorr=[z["log10_ecorr"]] * P, flags=[list(z["ecorr_flags"])] * P, coarsegrain=1.0 / 86400.0)
+    eng.set_red_noise([float(z["rn_log10_amp"]), -13.5, -14.2], [float(z["rn_gamma"]), 2.5, 4.0], components=30)
+    eng.prepare()
+    assert eng.n_toa == 7758 + 23023 + 35037
+    out = eng.generate(256).cpu().numpy()
+    assert out.shape == (256, eng.n_toa) and np.all(np.isfinite(out))
+    one = _fused_equals_replay(eng, 17)
+    assert np.array_equal(one, out[17])
+    # oracle on the dumped draws of one realisation, pulsar 0 (the real tim file)
+    d = eng.dump_draws(3)
+    tf = np.array([f["f"] for f in psrs[0].toas.flags])
+    n = int(eng.counts[0])
+    ref = po.measurement_noise_dt(eng.sigma_s[0], po.flag_vector(tf, z["efac_flags"], z["efac"], n),
+                                  po.flag_vector(tf, z["efac_flags"], 10 ** z["log10_equad"], n), *d["wn"][0])
+    epoch_of, ne, first, _ = po.quantize(eng.mjd[0], tf, dt=1.0 / 86400.0)
+    ref = ref + po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], tf, z["ecorr_flags"]), d["ecorr"][0])
+    ref = ref + po.red_noise_dt(psrs[0].toas.table["tdbld"], float(z["rn_log10_amp"]), float(z["rn_gamma"]), d["rn"][0])
+    assert relrms(out[3, :n], ref) < 1e-10
+    # ensemble statistics over 256 realisations: white + ECORR variance of the 430_ASP backend TOAs of pulsar 0
+    sel = np.where(tf == "430_ASP")[0]
+    k = list(z["efac_flags"]).index("430_ASP")
+    kj = list(z["ecorr_flags"]).index("430_ASP")
+    rn_part = eng.replay([eng.dump_draws(r) for r in range(8)], per_signal=True)["rn"].cpu().numpy()[:, sel]
+    white = out[:8, sel] - rn_part
+    expect = np.mean((z["efac"][k] * eng.sigma_s[0][sel]) ** 2 + (z["efac"][k] * 10 ** z["log10_equad"][k]) ** 2) + (10 ** z["log10_ecorr"][kj]) ** 2
+    assert abs(np.var(white) / expect - 1) < 0.15
+
+
+def test_config4_headline_array_with_cgw():
+    """68 x 5000 + one continuous-wave source (the reference test's CW parameters): the deterministic term is added
+    once per TOA and is identical in every realisation."""
+    from pta_replicator_amd.engine import ReplicaEngine
+    from bench import headline_array
+    psrs, noise = headline_array(68, 5000)
+    cw = dict(gwtheta=np.pi / 2, gwphi=2.5, mc=1e9, dist=5.0, fgw=1e-8, phase0=0.5, psi=1.5, inc=np.pi / 4, pdist=1.0,
+              pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=53000 * 86400)
+
+    def build(with_cw):
+        e = ReplicaEngine(psrs, seed=4)
+        e.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"])
+        e.set_jitter(log10_ecorr=noise["log10_ecorr"])
+        e.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"])
+        e.set_gwb(noise["gw_log10_A"], 13. / 3.)
+        if with_cw:
+            e.add_cgw(**cw)
+        return e.prepare()
+
+    a, b = build(True), build(False)
+    oa, ob = a.generate(3).cpu().numpy(), b.generate(3).cpu().numpy()
+    det = a.d_det.cpu().numpy()
+    assert np.max(np.abs((oa - ob) - det[None, :])) < 1e-12 * np.sqrt(np.mean(det ** 2))
+    for p in (0, 33, 67):   # oracle waveform on three pulsars
+        ra, dec = psrs[p].loc["RAJ"] * np.pi / 12, psrs[p].loc["DECJ"] * np.pi / 180
+        ref = po.cgw_dt(a.mjd[p], np.pi / 2 - dec, ra, **cw)
+        assert relrms(det[a.off[p]:a.off[p + 1]], ref) < 5e-10
+    _fused_equals_replay(a, 2)
+
+
+def test_config5_ska_scale_anisotropic():
+    """200 pulsars x 10000 TOAs, anisotropic GWB through the l <= 4 ORF basis: the 20100-pair basis evaluation that takes
+    the reference ~15 min of Python is one kernel launch; spot-checked pair by pair against the oracle."""
+    import time
+    import torch
+    from pta_replicator_amd import spharmORFbasis as anis
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    P, N, lmax = 200, 10000, 4
+    rng = np.random.default_rng(200)
+    raj, decj = rng.uniform(0, 24, P), np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
+    psrs = []
+    for a in range(P):
+        psr = SimulatedPulsar(toas=ArrayTOAs(np.sort(rng.uniform(53000, 60305, N)), 0.5), name=f"J{a:04d}", loc={"RAJ": raj[a], "DECJ": decj[a]})
+        make_ideal(psr)
+        psrs.append(psr)
+    locs = po.psr_locs_equatorial([p.loc for p in psrs])
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    basis = anis.correlated_basis_device(locs, lmax)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    assert dt < 5.0
+    basis = basis.cpu().numpy()
+    assert basis.shape == (25, P, P) and np.all(np.isfinite(basis)) and np.allclose(basis, basis.transpose(0, 2, 1), rtol=0, atol=0)
+    for (a, b) in ((0, 0), (3, 77), (150, 199), (42, 43), (9, 120)):
+        for ll in range(lmax + 1):
+            zeta = po.calczeta(locs[a, 0], locs[b, 0], locs[a, 1], locs[b, 1])
+            plus = [po.arbCompFrame_ORF(mm, ll, zeta) for mm in range(ll + 1)]
+            gamma_ml = [(-1) ** mm * plus[mm] for mm in range(1, ll + 1)][::-1] + plus
+            for mi in range(2 * ll + 1):
+                ref = po.real_rotated_Gammas(mi - ll, ll, locs[a, 0], locs[b, 0], locs[a, 1], locs[b, 1], gamma_ml)
+                assert abs(basis[ll * ll + mi, a, b] - ref) < 1e-9 * (abs(ref) + 0.03)
+    # anisotropy coefficients: isotropic term + 10 % perturbations, redrawn until the ORF is positive definite
+    crng = np.random.default_rng(200)
+    for _ in range(50):
+        clm = np.concatenate([[np.sqrt(4 * np.pi)], 0.1 * crng.standard_normal(24)])
+        orf = 2 * np.tensordot(clm, basis, axes=1)
+        if np.all(np.linalg.eigvalsh(orf) > 1e-6):
+            break
+    else:
+        pytest.fail("no positive-definite anisotropic ORF found")
+    eng = ReplicaEngine(psrs, seed=5)
+    eng.set_white_noise(efac=1.0, log10_equad=-6.5)
+    eng.set_red_noise(-14.0, 3.0)
+    eng.set_gwb(-14.6733, 13. / 3., clm=clm, lmax=lmax)
+    eng.prepare()
+    assert np.max(np.abs(eng.ORF.cpu().numpy() - orf)) < 1e-12
+    M = eng.d_M.cpu().numpy()
+    assert np.max(np.abs(M @ M.T - orf)) < 1e-12
+    out = eng.generate(2).cpu().numpy()
+    assert out.shape == (2, P * N) and np.all(np.isfinite(out))
+    _fused_equals_replay(eng, 1)
