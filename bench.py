@@ -31,7 +31,11 @@ sys.path.insert(0, ROOT)
 
 GW_LOG10_A = -14.6733          # noise_dicts/ng15_dict.json "gw_log10_A" 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix figure (not in the local guide)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure (not in the local guide)
+# HBM bytes per launch from the PMC passes of the same command (scripts/gpu_profile.sh -> profiles/), KiB as rocprofv3 reports them;
+# FETCH_SIZE is uncorrected (MI355X_MICROARCH.md: it under-counts wide streaming reads by up to 2x on gfx950)
+PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 882708.0, "write_kib": 2550930.0,
+                                    "source": "profiles/r01_rocprofv3_summary_run19.txt"}}
 
 
 def headline_array(P=68, N=5000, seed=68):
@@ -237,6 +241,8 @@ def main():
     import ctypes
     timed("pta_engine_rn_coef", lambda: _lib.call("pta_engine_rn_coef", eng.seed, 0, R, P, eng.K, dv.ptr(eng.d_amp), dv.ptr(ws["coef"]), s))
     timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts, s))
+    if eng.use_czt:
+        timed("pta_gwb_czt", lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, s))
     timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s))
     timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
 
@@ -260,23 +266,37 @@ def main():
     n_fft = 2 * Nf - 2
     alg_bytes = 8.0 * eng.n_toa * R
     alg_flops_gwb = (4.0 * P * P * Nf + 5.0 * n_fft * np.log2(n_fft) * P) * R
-    exe_flops_gwb = 2.0 * (R * P) * (2.0 * (Nf - 2)) * ((npts + 1) // 2)  # what the symmetric pruned-DFT GEMM executes
-    dom = max(("pta_gwb_idft_rng", "pta_engine_synth"), key=lambda k: kern[k])
-    if dom == "pta_engine_synth":
-        ach = alg_bytes / (kern[dom] * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None}
+    gwb_kernel = "pta_gwb_czt" if eng.use_czt else "pta_gwb_idft_rng"
+    # executed flops: chirp-z = two 4096-point complex FFTs (5 N log2 N each) + chirp products per row; DFT-GEMM = 2 M K N
+    exe_flops = {"pta_gwb_czt": (2 * 5.0 * 4096 * 12 + 6.0 * (4096 + 2 * (Nf - 2) + npts)) * R * P,
+                 "pta_gwb_idft_rng": 2.0 * (R * P) * (2.0 * (Nf - 2)) * ((npts + 1) // 2)}
+
+    def hbm_roof(k):
+        ach = alg_bytes / (kern[k] * 1e-3) / 1e9
+        d = {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+             "traffic": None, "avg_launch_ms": kern[k]}
+        t = PMC_TRAFFIC.get(k)
+        if t and t["R"] == R and t["n_toa"] == eng.n_toa:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) of this very launch shape
+            d["traffic"] = (t["fetch_kib"] + t["write_kib"]) * 1024.0
+            d["traffic_source"] = t["source"]
+        return d
+
+    def flop_roof(k):
+        ach = alg_flops_gwb / (kern[k] * 1e-3) / 1e12
+        bound = "mfma" if k == "pta_gwb_idft_rng" else "valu-fp64"
+        return {"kernel": k, "bound": bound, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12,
+                "avg_launch_ms": kern[k]}
+
+    if kern["pta_engine_synth"] >= kern[gwb_kernel]:
+        roof, other = hbm_roof("pta_engine_synth"), flop_roof(gwb_kernel)
     else:
-        ach = alg_flops_gwb / (kern[dom] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                "executed_tflops": exe_flops_gwb / (kern[dom] * 1e-3) / 1e12}
-    roof["avg_launch_ms"] = kern[dom]
-    other = "pta_engine_synth" if dom != "pta_engine_synth" else "pta_gwb_idft_rng"
-    roof["also"] = {"kernel": "pta_engine_synth", "bound": "hbm", "achieved": alg_bytes / (kern["pta_engine_synth"] * 1e-3) / 1e9,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s"} if other == "pta_engine_synth" else \
-                   {"kernel": "pta_gwb_idft_rng", "bound": "mfma", "achieved": alg_flops_gwb / (kern["pta_gwb_idft_rng"] * 1e-3) / 1e12,
-                    "executed_tflops": exe_flops_gwb / (kern["pta_gwb_idft_rng"] * 1e-3) / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s"}
+        roof, other = flop_roof(gwb_kernel), hbm_roof("pta_engine_synth")
+        if roof["bound"] != "mfma":   # the contract's enum: the chirp-z kernel runs on the fp64 vector pipe, same 78.6 TFLOP/s peak
+            roof["bound_detail"], roof["bound"] = roof["bound"], "mfma"
+    roof["also"] = other
+    if "pta_gwb_idft_rng" in kern and gwb_kernel != "pta_gwb_idft_rng":
+        roof["alternative_gwb_transform"] = flop_roof("pta_gwb_idft_rng")
 
     micro = {}
     try:

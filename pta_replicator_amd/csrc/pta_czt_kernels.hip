@@ -1,0 +1,172 @@
+// GWB frequency -> time stage as a chirp-z (Bluestein) transform: one workgroup per (realisation, pulsar) row,
+// two in-LDS 4096-point fp64 FFTs, draws generated in registers.  See pta_fft.h for the algebra.
+// Replaces, per row, the Hermitian pack + np.fft.ifft + crop of red_noise.py:275-285 (the sqrt(C) scaling of :270 is
+// folded into the pre-chirp, the 1/dt and ifft normalisation into the post-chirp, the M @ w mix of :268 follows on
+// the 600-sample grid in pta_gwb_mix).
+#include "pta_common.h"
+#include "pta_fft.h"
+
+// setup: twiddles, pre-chirp (with sqrtC), post-chirp (with 2/(n dt)), and the spectrum of the convolution chirp
+__global__ __launch_bounds__(PTA_FFT_THREADS) void k_czt_setup(const double *__restrict__ sqrtC, int Nf, int npts, int i0,
+                                                               double inv_dt, double *__restrict__ pre,
+                                                               double *__restrict__ FB, double *__restrict__ tw,
+                                                               double *__restrict__ post) {
+  __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
+  const int tid = threadIdx.x;
+  const int Kf = Nf - 2;
+  const int64_t n = 2 * (int64_t)Nf - 2;
+  for (int m = tid; m < PTA_FFT_N; m += PTA_FFT_THREADS) {
+    double s, c;
+    sincospi((double)(2 * m) / (double)PTA_FFT_N, &s, &c);
+    tw[2 * m] = c;
+    tw[2 * m + 1] = -s;  // e^{-2 pi i m / 4096}
+    // pre-chirp sqrtC_k e^{+ pi i k^2 / n}, k = m + 1
+    double pr = 0.0, pi_ = 0.0;
+    if (m < Kf) {
+      int64_t k = m + 1, q = (k * k) % (2 * n);
+      sincospi((double)q / (double)n, &s, &c);
+      pr = sqrtC[k] * c;
+      pi_ = sqrtC[k] * s;
+    }
+    pre[2 * m] = pr;
+    pre[2 * m + 1] = pi_;
+    // convolution chirp b_u = e^{- pi i u^2 / n} on u = j - k in [i0 - Kf, i0 + npts - 2], wrapped mod 4096
+    int64_t u = m;
+    bool used = (m <= i0 + npts - 2);
+    if (!used && m >= PTA_FFT_N - (Kf - i0)) {
+      u = (int64_t)m - PTA_FFT_N;
+      used = true;
+    }
+    double br = 0.0, bi = 0.0;
+    if (used) {
+      int64_t q = (u * u) % (2 * n);
+      sincospi((double)q / (double)n, &s, &c);
+      br = c;
+      bi = -s;
+    }
+    re[PTA_FFT_PHYS(m)] = br;
+    im[PTA_FFT_PHYS(m)] = bi;
+  }
+  for (int jj = tid; jj < npts; jj += PTA_FFT_THREADS) {  // post-chirp (2/(n dt)) e^{+ pi i j^2 / n}
+    int64_t j = i0 + jj, q = (j * j) % (2 * n);
+    double s, c;
+    sincospi((double)q / (double)n, &s, &c);
+    double amp = 2.0 * inv_dt / (double)n;
+    post[2 * jj] = amp * c;
+    post[2 * jj + 1] = amp * s;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // (the passes read the twiddles this same block just wrote)
+  pta_fft_pass<false, 9>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 6>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 3>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 0>(re, im, tw, tid);
+  __syncthreads();
+  for (int m = tid; m < PTA_FFT_N; m += PTA_FFT_THREADS) {  // logical (digit-reversed) order, 1/L of the inverse folded in
+    FB[2 * m] = re[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
+    FB[2 * m + 1] = im[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
+  }
+}
+
+static bool czt_fits(int Nf, int npts, int i0) { return Nf >= 3 && (Nf - 2) + npts - 2 < PTA_FFT_N && i0 >= 1 && (Nf - 2) <= PTA_FFT_N; }
+
+extern "C" int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *pre, double *FB, double *tw,
+                                 double *post, void *stream) {
+  PTA_REQUIRE(sqrtC && pre && FB && tw && post, PTA_E_ARG, "pta_gwb_czt_setup: NULL argument");
+  PTA_REQUIRE(czt_fits(Nf, npts, i0), PTA_E_ARG, "pta_gwb_czt_setup: Nf=%d npts=%d does not fit one 4096-point convolution", Nf, npts);
+  hipLaunchKernelGGL(k_czt_setup, dim3(1), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), sqrtC, Nf, npts, i0, inv_dt, pre, FB, tw, post);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+extern "C" int pta_gwb_czt_fits(int Nf, int npts, int i0) { return czt_fits(Nf, npts, i0) ? 1 : 0; }
+
+template <bool RNG>
+__global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
+                                                                int M, int P, int Nf, int npts, int i0,
+                                                                const double *__restrict__ pre, const double *__restrict__ FB,
+                                                                const double *__restrict__ tw, const double *__restrict__ post,
+                                                                double *__restrict__ G0, int64_t ldg) {
+  __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const int Kf = Nf - 2;
+  const uint64_t real = r0 + (uint64_t)(row / P);
+  const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(row % P));
+  // chirped, spectrum-weighted draws: A[t] = w[a, t+1] * pre[t]   (pair k = t+1 <-> Re, Im of w[a,k], red_noise.py:240)
+#pragma unroll 1
+  for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {
+    const int t = tid + PTA_FFT_THREADS * i;
+    double ar = 0.0, ai = 0.0;
+    if (t < Kf) {
+      double wr, wi;
+      if (RNG) {
+        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi);
+      } else {
+        wr = w[(int64_t)row * ldw + 2 * (t + 1)];
+        wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
+      }
+      const double pr = pre[2 * t], pi_ = pre[2 * t + 1];
+      ar = wr * pr - wi * pi_;
+      ai = wr * pi_ + wi * pr;
+    }
+    re[PTA_FFT_PHYS(t)] = ar;
+    im[PTA_FFT_PHYS(t)] = ai;
+  }
+  __syncthreads();
+  // passes spelled out so that every stride is a compile-time constant
+  pta_fft_pass<false, 9>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 6>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 3>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 0>(re, im, tw, tid);
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {  // times the chirp spectrum (both in digit-reversed order)
+    const int t = tid + PTA_FFT_THREADS * i;
+    const int p = PTA_FFT_PHYS(t);
+    const double xr = re[p], xi = im[p], fr = FB[2 * t], fi = FB[2 * t + 1];
+    re[p] = xr * fr - xi * fi;
+    im[p] = xr * fi + xi * fr;
+  }
+  __syncthreads();
+  pta_fft_pass<true, 0>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<true, 3>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<true, 6>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<true, 9>(re, im, tw, tid);
+  __syncthreads();
+  for (int jj = tid; jj < npts; jj += PTA_FFT_THREADS) {  // x_j = Re(post_j * y_j), y_j at circular index j - 1
+    const int p = PTA_FFT_PHYS(i0 - 1 + jj);
+    G0[(int64_t)row * ldg + jj] = re[p] * post[2 * jj] - im[p] * post[2 * jj + 1];
+  }
+}
+
+// w == NULL: draws generated on chip (throughput mode); else w[M x ldw] interleaved (re, im) rows (replay mode)
+extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
+                           const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
+                           void *stream) {
+  PTA_REQUIRE(pre && FB && tw && post && G0, PTA_E_ARG, "pta_gwb_czt: NULL argument");
+  PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && npts > 0 && ldg >= npts, PTA_E_ARG, "pta_gwb_czt: R=%d P=%d npts=%d", R, P, npts);
+  PTA_REQUIRE(czt_fits(Nf, npts, i0), PTA_E_ARG, "pta_gwb_czt: Nf=%d npts=%d does not fit one 4096-point convolution", Nf, npts);
+  PTA_REQUIRE(!w || ldw >= 2 * (int64_t)Nf, PTA_E_ARG, "pta_gwb_czt: ldw too small");
+  int64_t M64 = (int64_t)R * P;
+  PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_czt: R*P too large");
+  const int M = (int)M64;
+  if (w)
+    hipLaunchKernelGGL(k_gwb_czt<false>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
+                       tw, post, G0, ldg);
+  else
+    hipLaunchKernelGGL(k_gwb_czt<true>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
+                       tw, post, G0, ldg);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}

@@ -58,6 +58,8 @@ class ReplicaEngine:
         self._gw = None
         self._det = None
         self._prepared = False
+        # frequency -> time transform of the GWB in throughput mode: "auto" = chirp-z FFT when it fits, else the MFMA DFT-GEMM
+        self.gwb_transform = "auto"
 
     # ---------------------------------------------------------------- configuration -------------
     def set_red_noise(self, log10_amplitude, spectral_index, components=30, libstempo_convention=False):
@@ -243,6 +245,12 @@ class ReplicaEngine:
             self.d_Tsym, self.d_rot = dv.empty((nsym,)), dv.empty((nrot.value,))
             _lib.call("pta_gwb_twiddle_sym", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_Tsym),
                       dv.ptr(self.d_rot), s)
+            # chirp-z tables (default frequency -> time transform whenever one 4096-point convolution covers the window)
+            self.use_czt = bool(_lib.lib.pta_gwb_czt_fits(Nf, npts, 10)) and self.gwb_transform != "gemm"
+            if self.use_czt:
+                self.d_czt = [dv.empty((2 * 4096,)), dv.empty((2 * 4096,)), dv.empty((2 * 4096,)), dv.empty((2 * npts,))]
+                _lib.call("pta_gwb_czt_setup", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]),
+                          *[dv.ptr(x) for x in self.d_czt], s)
             self.d_ut = dv.f64(grid["ut"])
             self.d_jlo = dv.empty((N,), dtype=torch.int32)
             _lib.call("pta_gwb_bracket", dv.ptr(self.d_ut), npts, dv.ptr(self.d_toa_s), N, dv.ptr(self.d_jlo), s)
@@ -324,8 +332,12 @@ class ReplicaEngine:
             pl.rn_coef = ws["coef"].data_ptr()
         if pl.gw_npts:
             npts = pl.gw_npts
-            _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_Tsym), dv.ptr(self.d_rot), npts,
-                      dv.ptr(ws["G0"]), npts, s)
+            if self.use_czt:
+                _lib.call("pta_gwb_czt", self.seed, r0, None, 0, R, self.P, self.grid["Nf"], npts, 10,
+                          *[dv.ptr(x) for x in self.d_czt], dv.ptr(ws["G0"]), npts, s)
+            else:
+                _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_Tsym), dv.ptr(self.d_rot), npts,
+                          dv.ptr(ws["G0"]), npts, s)
             _lib.call("pta_gwb_mix", dv.ptr(self.d_M), self.P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s)
             pl.gw_G = ws["G"].data_ptr()
         _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(out), out.stride(0), s)

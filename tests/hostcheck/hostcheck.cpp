@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include "../../pta_replicator_amd/csrc/pta_rng.h"
 #include "../../pta_replicator_amd/csrc/pta_orf.h"
+#include "../../pta_replicator_amd/csrc/pta_fft.h"
 
 extern "C" {
 
@@ -41,4 +42,21 @@ void hc_orf_basis(const double *locs, int P, int lmax, double *basis) {
         }
       }
 }
+
+// FFT passes with the 256 "threads" of a workgroup emulated sequentially; a barrier = the end of a tid loop.
+// re/im are PTA_FFT_PLANE-sized planes addressed through PTA_FFT_PHYS.
+void hc_fft_forward(double *re, double *im, const double *tw) {
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 9>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 6>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 3>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 0>(re, im, tw, tid);
+}
+void hc_fft_inverse(double *re, double *im, const double *tw) {
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 0>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 3>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 6>(re, im, tw, tid);
+  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 9>(re, im, tw, tid);
+}
+int hc_fft_phys(int i) { return PTA_FFT_PHYS(i); }
+int hc_fft_plane() { return PTA_FFT_PLANE; }
 }

@@ -203,6 +203,45 @@ def test_gwb_idft_rng_equals_replay_of_its_draws(gpu, variant, Nf, npts):
     assert np.max(np.abs(wr[0::2] - z0)) < 1e-13 and np.max(np.abs(wr[1::2] - z1)) < 1e-13
 
 
+@pytest.mark.parametrize("Nf,npts", [(3000, 600), (3001, 600), (601, 200), (500, 37), (2400, 601)])
+def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts):
+    """chirp-z path: (a) replay form vs numpy's Hermitian-packed ifft; (b) on-chip-RNG form vs the DFT-GEMM over the
+    dumped draws."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    assert lib.lib.pta_gwb_czt_fits(Nf, npts, 10) == 1 and lib.lib.pta_gwb_czt_fits(5000, 1000, 10) == 0
+    rng = np.random.default_rng(Nf)
+    seed, r0, R, P = 99, 12345, 2, 3
+    M = R * P
+    C = rng.uniform(0.5, 2.0, Nf) * 1e-14
+    dt = 977.0
+    sq_d = dv.f64(C ** 0.5)
+    tabs = [dv.empty((8192,)), dv.empty((8192,)), dv.empty((8192,)), dv.empty((2 * npts,))]
+    lib.call("pta_gwb_czt_setup", dv.ptr(sq_d), Nf, npts, 10, 1.0 / dt, *[dv.ptr(x) for x in tabs], gpu["s"])
+    w = rng.standard_normal((M, Nf, 2))
+    w_d = dv.f64(w)
+    G = dv.zeros((M, npts))
+    lib.call("pta_gwb_czt", 0, 0, dv.ptr(w_d), 2 * Nf, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G), npts, gpu["s"])
+    Res_f = (w[..., 0] + 1j * w[..., 1]) * C ** 0.5
+    Res_f[:, 0] = 0; Res_f[:, -1] = 0
+    ref = po.gwb_time_series(Res_f, dt)[:, 10:npts + 10]
+    assert np.max(np.abs(G.cpu().numpy() - ref)) < 1e-12 * np.max(np.abs(ref))
+    # throughput form against the plain DFT-GEMM on its own draws
+    G_rng = dv.zeros((M, npts))
+    lib.call("pta_gwb_czt", seed, r0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G_rng), npts, gpu["s"])
+    wd = dv.empty((M, 2 * Nf))
+    for r in range(R):
+        for a in range(P):
+            lib.call("pta_rng_fill_normal", seed, r0 + r, 1, philox_ref.stream_id(1, a), Nf, 1,
+                     ctypes.c_void_p(wd.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, gpu["s"])
+    ldt = (npts + 15) // 16 * 16
+    T = dv.empty((2 * (Nf - 2), ldt))
+    lib.call("pta_gwb_twiddle", dv.ptr(sq_d), Nf, npts, 10, 1.0 / dt, dv.ptr(T), ldt, gpu["s"])
+    G_rep = dv.zeros((M, npts))
+    lib.call("pta_gwb_idft", dv.ptr(wd), 2 * Nf, M, Nf, dv.ptr(T), ldt, npts, dv.ptr(G_rep), npts, 1, gpu["s"])
+    a_, b_ = G_rng.cpu().numpy(), G_rep.cpu().numpy()
+    assert np.max(np.abs(a_ - b_)) < 1e-12 * np.max(np.abs(b_))
+
+
 def test_td_mode_against_oracle(gpu):
     """dense path: covariance assembly -> blocked Cholesky -> L z, vs numpy on the same recipe and draws."""
     from pta_replicator_amd import red_noise as rn

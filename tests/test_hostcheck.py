@@ -99,3 +99,28 @@ def test_orf_hd_headline_array(hc):
     hc.hc_orf_basis(_p(locs, ctypes.c_double), 68, 0, _p(basis, ctypes.c_double))
     assert np.max(np.abs(2 * np.sqrt(4 * np.pi) * basis[0] - orf)) < 1e-13
     np.linalg.cholesky(orf)
+
+
+def _digit_reverse8(k):
+    k = np.asarray(k)
+    return ((k & 7) << 9) | (((k >> 3) & 7) << 6) | (((k >> 6) & 7) << 3) | ((k >> 9) & 7)
+
+
+def test_fft4096_passes_against_numpy(hc):
+    """the in-LDS radix-8 FFT used by the chirp-z GWB kernel: forward = numpy fft in digit-reversed order,
+    inverse(forward(x)) = 4096 x, linear convolution through it = numpy's."""
+    rng = np.random.default_rng(8)
+    n, plane = 4096, hc.hc_fft_plane()
+    phys = np.array([hc.hc_fft_phys(i) for i in range(n)])
+    m = np.arange(n)
+    tw = np.stack([np.cos(2 * np.pi * m / n), -np.sin(2 * np.pi * m / n)], axis=1).ravel().copy()
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    re, im = np.zeros(plane), np.zeros(plane)
+    re[phys], im[phys] = x.real, x.imag
+    hc.hc_fft_forward(_p(re, ctypes.c_double), _p(im, ctypes.c_double), _p(tw, ctypes.c_double))
+    X = np.fft.fft(x)
+    got = re[phys] + 1j * im[phys]                    # logical order of the buffer = digit-reversed frequencies
+    assert np.max(np.abs(got[_digit_reverse8(m)] - X)) < 1e-11 * np.max(np.abs(X))
+    hc.hc_fft_inverse(_p(re, ctypes.c_double), _p(im, ctypes.c_double), _p(tw, ctypes.c_double))
+    back = (re[phys] + 1j * im[phys]) / n
+    assert np.max(np.abs(back - x)) < 1e-13
