@@ -2,6 +2,7 @@
 // red_noise.py:235; the same factorisation serves TD mode's N_toa x N_toa covariances).
 #include "pta_common.h"
 #include "pta_orf.h"
+#include "pta_mfma.h"
 
 // ---- ORF ---------------------------------------------------------------------------------------
 __global__ void k_orf_hd(const double *__restrict__ locs, int P, double *__restrict__ orf) {
@@ -97,8 +98,22 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, in
     }
   }
   __syncthreads();
+  // inverse of the factored block for the MFMA panel solve: column j of L^{-1} by forward substitution, one thread per
+  // column.  Its strictly lower part is parked TRANSPOSED in the strict upper triangle of the block (free until
+  // k_zero_upper clears it); its diagonal is 1/diag(L) and is recomputed by the consumer.
+  __shared__ double T[CH_NB][CH_LD];
+  if (t < nb) {
+    const int j = t;
+    T[j][j] = 1.0 / S[j][j];
+    for (int i = j + 1; i < nb; ++i) {
+      double acc = 0.0;
+      for (int q = j; q < i; ++q) acc = fma(S[i][q], T[q][j], acc);
+      T[i][j] = -acc / S[i][i];
+    }
+  }
+  __syncthreads();
   for (int i = t >> 6; i < nb; i += 4)
-    for (int c = t & 63; c < nb; c += 64) M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : 0.0;
+    for (int c = t & 63; c < nb; c += 64) M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : T[c][i];
 }
 
 __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int k0, int nb) {
@@ -126,6 +141,57 @@ __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int
   __syncthreads();
   for (int i = t >> 6; i < rows; i += 4)
     for (int c = t & 63; c < nb; c += 64) M[(int64_t)(r0 + i) * n + (k0 + c)] = X[i][c];
+}
+
+// Panel solve on the matrix cores: X <- X L11^{-T} = X . Linv^T, 64 rows per workgroup, K = 64.
+// Both operands sit row-major ("m-major") in LDS with an odd pitch, so the 16-lane fragment reads (one row each)
+// fall on distinct banks and the tile loads need no transposition.
+__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n, int k0, int nb) {
+  __shared__ double Li[CH_NB][CH_LD];  // Li[c][t] = (L11^{-1})[c][t], zero for t > c
+  __shared__ double X[CH_NB][CH_LD];
+  double *M = A + (int64_t)blockIdx.y * n * n;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int r0 = k0 + nb + blockIdx.x * CH_NB;
+  const int rows = min(CH_NB, n - r0);
+  for (int i = t >> 6; i < CH_NB; i += 4)
+    for (int c = t & 63; c < CH_NB; c += 64) {
+      double v = 0.0;
+      if (i < nb && c < nb) {
+        if (c < i) v = M[(int64_t)(k0 + c) * n + (k0 + i)];        // parked transposed in the upper triangle
+        else if (c == i) v = 1.0 / M[(int64_t)(k0 + i) * n + (k0 + i)];
+      }
+      Li[i][c] = v;
+      X[i][c] = (i < rows && c < nb) ? M[(int64_t)(r0 + i) * n + (k0 + c)] : 0.0;
+    }
+  __syncthreads();
+  const int wm = w >> 1, wn = w & 1;
+  pta_f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+  for (int kk = 0; kk < CH_NB; kk += 4) {
+    double a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = X[wm * 32 + i * 16 + (l & 15)][kk + (l >> 4)];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = Li[wn * 32 + j * 16 + (l & 15)][kk + (l >> 4)];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int row = wm * 32 + i * 16 + pta_mfma_row(l, r);
+        int col = wn * 32 + j * 16 + pta_mfma_col(l);
+        if (row < rows && col < nb) M[(int64_t)(r0 + row) * n + (k0 + col)] = acc[i][j][r];
+      }
 }
 
 __global__ void k_zero_upper(double *__restrict__ A, int n) {
@@ -160,7 +226,10 @@ extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *s
       PTA_LAUNCH_CHECK();
       const int rows = n - j0 - nb;
       if (rows <= 0) continue;
-      hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
+      if (g_gemm_algo)
+        hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
+      else
+        hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
       PTA_LAUNCH_CHECK();
       const int pcols = pend - (j0 + nb);  // columns of the outer panel still to be factored
       if (pcols > 0) {

@@ -60,7 +60,7 @@ def test_rng_fill_matches_numpy_twin(gpu, interleave):
         assert np.max(np.abs(got0[r] - e0)) < 1e-13 and np.max(np.abs(got1[r] - e1)) < 1e-13
 
 
-@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (70, 130, 37), (200, 600, 301), (3, 600, 2998)])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (70, 130, 37), (200, 600, 301), (3, 600, 2998), (300, 257, 75), (515, 400, 64)])
 @pytest.mark.parametrize("transB", [0, 1])
 def test_dgemm_mfma_and_valu(gpu, shape, transB):
     dv, lib = gpu["dv"], gpu["lib"]
