@@ -184,6 +184,16 @@ int pta_gwb_interp(const double *G, int64_t ldg, int P, int npts, const double *
 #define PTA_CGW_NPAR 18
 int pta_cgw(const double *mjd, int N, const double *par_host, double *out, int accumulate, void *stream);
 
+/* Catalogue of N_cw continuous-wave sources for one pulsar (add_catalog_of_cws and its numba kernels,
+ * deterministic.py:188-561): out[i] (+)= sum_c waveform_c(mjd[i]), NaN terms dropped (:435,:556).
+ * sources[c*8 + 0..7] = gwtheta, gwphi, mc [Msun], dist [Mpc], fgw [Hz], phase0, psi, inc (device);
+ * phat_host[3] the pulsar unit vector; unit_consts_host = {SOLAR2S, KPC2S, MPC2S} (constants.py:6-8);
+ * mode 0 evolve / 1 phase_approx / 2 monochromatic.  Workspaces sized by pta_cw_catalog_workspace (doubles). */
+int pta_cw_catalog_workspace(int N, int ncw, int64_t *par_doubles, int64_t *partial_doubles, int *nchunk);
+int pta_cw_catalog(const double *mjd, int N, const double *sources, int ncw, const double *phat_host,
+                   const double *unit_consts_host, double pdist_kpc, int use_pphase, double pphase, int psr_term, int mode,
+                   double tref, double *par_ws, double *partial_ws, double *out, int accumulate, void *stream);
+
 /* ---------------------------------------------------------------- fused engine ----- */
 /* One pass that writes R whole-array realisations: out[r, i] = RN + GWB + WN + ECORR + det,
  * every deviate generated on chip (throughput mode).  All arrays are device pointers; any

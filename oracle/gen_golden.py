@@ -23,6 +23,7 @@ variants.npz     the branches the shipped vector does not pin: t
                  no_correlations, lmax=2, tnequad, per-flag WN/ECORR with multi-TOA epochs,
                  default RN convention, every add_cgw branch.
 c3_mini.npz      a 6-pulsar miniature of config 3 (HD GWB + RN + EFAC/EQUAD + ECORR, notebook seeds).
+cw_catalog.npz   add_catalog_of_cws through both numba kernels of the reference (40 and 1200 sources).
 """
 import glob
 import json
@@ -342,6 +343,36 @@ def gen_c3_mini(ref):
     print("c3_mini: Nf =", int(out["Nf"]))
 
 
+def gen_cw_catalog(ref):
+    """add_catalog_of_cws (deterministic.py:188-561): 40 sources through loop_over_CWs and 1200 through the
+    >1000-source branch loop_over_CWs_parallel (numba is stubbed, so both run as plain Python), incl. two binaries that
+    have already merged (NaN terms that the reference zeroes)."""
+    psrs, mjd0 = synth_array(ref, 3, 200, seed=99, burst=1, backends=("X",))
+    out = pulsar_inputs("", psrs, mjd0)
+    rng = np.random.default_rng(7)
+    for tag, ncw in (("small_", 40), ("large_", 1200)):
+        src = dict(gwtheta=np.arccos(rng.uniform(-1, 1, ncw)), gwphi=rng.uniform(0, 2 * np.pi, ncw),
+                   mc=10 ** rng.uniform(8.0, 9.5, ncw), dist=10 ** rng.uniform(1.0, 3.0, ncw), fgw=10 ** rng.uniform(-8.8, -7.5, ncw),
+                   phase0=rng.uniform(0, 2 * np.pi, ncw), psi=rng.uniform(0, np.pi, ncw), inc=np.arccos(rng.uniform(-1, 1, ncw)))
+        src["mc"][3] = 3e10; src["fgw"][3] = 4e-7      # merges within the data span: NaN terms
+        src["mc"][11] = 2e10; src["fgw"][11] = 6e-7
+        for k, v in src.items():
+            out[tag + k] = v
+        for case, kw in (("evolve", dict(pdist=1.2, psrTerm=True, evolve=True)), ("mono", dict(pdist=0.8, psrTerm=True, evolve=False)),
+                         ("approx", dict(pdist=1.0, psrTerm=True, evolve=False, phase_approx=True)),
+                         ("earth", dict(pdist=1.0, psrTerm=False, evolve=True)), ("pphase", dict(pphase=1.7, psrTerm=True, evolve=True))):
+            if tag == "large_" and case not in ("evolve", "mono"):
+                continue
+            ps, _ = synth_array(ref, 3, 200, seed=99, burst=1, backends=("X",))
+            with np.errstate(invalid="ignore"):
+                for p in ps:
+                    ref.deterministic.add_catalog_of_cws(p, src["gwtheta"], src["gwphi"], src["mc"], src["dist"], src["fgw"], src["phase0"],
+                                                         src["psi"], src["inc"], tref=53000 * 86400, **kw)
+            out[tag + case] = np.array([sig(p, "cw_catalog") for p in ps])
+    np.savez_compressed(os.path.join(OUT, "cw_catalog.npz"), **out)
+    print("cw_catalog:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = rr.load_reference()
@@ -350,5 +381,6 @@ if __name__ == "__main__":
     gen_orf(ref)
     gen_variants(ref)
     gen_c3_mini(ref)
+    gen_cw_catalog(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

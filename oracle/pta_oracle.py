@@ -555,6 +555,20 @@ def cgw_dt(mjd, ptheta, pphi, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, p
     return -fplus * rplus - fcross * rcross
 
 
+def cw_catalog_dt(mjd, ptheta, pphi, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_list, phase0_list, psi_list, inc_list,
+                  pdist=1.0, pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=0):
+    """sum over sources of the single-source waveform with NaN -> 0, in catalogue order (add_catalog_of_cws and
+    loop_over_CWs, deterministic.py:188-318, :443-561; the parallel variant :321-440 sums the same terms)."""
+    res = np.zeros(len(mjd))
+    for i in range(len(mc_list)):
+        with np.errstate(invalid="ignore"):
+            rrr = cgw_dt(mjd, ptheta, pphi, gwtheta_list[i], gwphi_list[i], mc_list[i], dist_list[i], fgw_list[i], phase0_list[i],
+                         psi_list[i], inc_list[i], pdist=pdist, pphase=pphase, psrTerm=psrTerm, evolve=evolve,
+                         phase_approx=phase_approx, tref=tref)
+        res += np.where(np.isnan(rrr), 0.0, rrr)
+    return res
+
+
 # ----------------------------------------------------------------------------------------
 # time-domain ("TD") mode oracle: dense covariance -> Cholesky -> L z   (SURVEY.md §7, App. A.1)
 # ----------------------------------------------------------------------------------------

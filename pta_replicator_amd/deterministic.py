@@ -1,10 +1,13 @@
-"""Continuous-wave injection on the MI355X: ``add_cgw`` with the reference's signature.
+"""Continuous-wave injection on the MI355X: ``add_cgw`` and ``add_catalog_of_cws`` with the reference's signatures.
 
-Mirrors ``pta_replicator/deterministic.py:13-185``.  The scalar prefactors (antenna patterns, chirp factors) are
-computed on the host with the reference's own expressions; the per-TOA waveform (four pow, two sincos) runs in
-the ``pta_cgw`` kernel.  The catalogue / burst / memory injectors of the reference are outside this round's scope
-(SURVEY.md §8f).
+Mirrors ``pta_replicator/deterministic.py:13-185`` (single source) and ``:188-561`` (catalogue + its two numba
+kernels).  For a single source the scalar prefactors (antenna patterns, chirp factors) are computed on the host with
+the reference's own expressions and the per-TOA waveform (four pow, two sincos) runs in the ``pta_cgw`` kernel; for a
+catalogue everything, prefactors included, runs on the device (``pta_cw_catalog``).  The population / burst / memory
+injectors of the reference remain outside this round's scope.
 """
+import ctypes
+
 import numpy as np
 
 from . import _lib, device as dv
@@ -82,5 +85,40 @@ def add_cgw(psr, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, pdist=1.0, pph
                              {"gwtheta": gwtheta, "gwphi": gwphi, "mc": mc_s, "dist": dist_s, "fgw": fgw,
                               "phase0": phase0_orb, "psi": psi, "inc": inc, "pdist": pdist, "pphase": pphase,
                               "psrTerm": psrTerm, "evolve": evolve, "phase_approx": phase_approx, "tref": tref}, dt)
+    psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
+    psr.update_residuals()
+
+
+def add_catalog_of_cws(psr, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_list, phase0_list, psi_list, inc_list, pdist=1.0,
+                       pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=0, chunk_size=10_000_000,
+                       signal_name="cw_catalog"):
+    """Add many SMBHB continuous-wave sources at once; same arguments as deterministic.py:188-229 (arrays of source
+    parameters, one entry per binary).  ``chunk_size`` is accepted for compatibility: the device sums the whole
+    catalogue in one pass (the reference re-registers the signal for every chunk, which raises on the second one)."""
+    ra, dec = ra_dec(psr)
+    ptheta, pphi = np.pi / 2 - dec, ra
+    phat = np.array([np.sin(ptheta) * np.cos(pphi), np.sin(ptheta) * np.sin(pphi), np.cos(ptheta)], dtype=np.float64)
+    lists = [np.asarray(x, dtype=np.float64).ravel() for x in (gwtheta_list, gwphi_list, mc_list, dist_list, fgw_list,
+                                                                  phase0_list, psi_list, inc_list)]
+    ncw = len(lists[0])
+    if any(len(x) != ncw for x in lists):
+        raise ValueError("all source parameter lists must have the same length")
+    mjd = np.asarray(psr.toas.get_mjds().value, dtype=np.float64)
+    n = len(mjd)
+    src_d, mjd_d = dv.f64(np.stack(lists, axis=1)), dv.f64(mjd)
+    npar, npart, nchunk = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+    _lib.call("pta_cw_catalog_workspace", n, ncw, ctypes.byref(npar), ctypes.byref(npart), ctypes.byref(nchunk))
+    par_ws, part_ws, out = dv.empty((npar.value,)), dv.empty((npart.value,)), dv.empty((n,))
+    consts = np.array([SOLAR2S, KPC2S, MPC2S], dtype=np.float64)
+    mode = 0 if evolve else (1 if phase_approx else 2)
+    _lib.call("pta_cw_catalog", dv.ptr(mjd_d), n, dv.ptr(src_d), ncw, dv.hptr(phat), dv.hptr(consts), ctypes.c_double(pdist),
+              0 if pphase is None else 1, ctypes.c_double(0.0 if pphase is None else pphase), 1 if psrTerm else 0, mode,
+              ctypes.c_double(tref), dv.ptr(par_ws), dv.ptr(part_ws), dv.ptr(out), 0, dv.stream_ptr())
+    dt = out.cpu().numpy() * u.s
+    psr.update_added_signals("{}_".format(psr.name) + signal_name,
+                             {"gwtheta_list": gwtheta_list, "gwphi_list": gwphi_list, "mc_list": mc_list, "dist_list": dist_list,
+                              "fgw_list": fgw_list, "phase0_list": phase0_list, "psi_list": psi_list, "inc_list": inc_list,
+                              "pdist": pdist, "pphase": pphase, "psrTerm": psrTerm, "evolve": evolve, "phase_approx": phase_approx,
+                              "tref": tref}, dt)
     psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
     psr.update_residuals()

@@ -201,6 +201,28 @@ def test_cgw_branches(tag, kw):
         assert relrms(cw, z[tag][a]) < 1e-11
 
 
+@pytest.mark.parametrize("tag,case,kw", [
+    ("small_", "evolve", dict(pdist=1.2, psrTerm=True, evolve=True)),
+    ("small_", "mono", dict(pdist=0.8, psrTerm=True, evolve=False)),
+    ("small_", "approx", dict(pdist=1.0, psrTerm=True, evolve=False, phase_approx=True)),
+    ("small_", "earth", dict(pdist=1.0, psrTerm=False, evolve=True)),
+    ("small_", "pphase", dict(pphase=1.7, psrTerm=True, evolve=True)),
+    ("large_", "evolve", dict(pdist=1.2, psrTerm=True, evolve=True)),
+])
+def test_cw_catalog(tag, case, kw):
+    """add_catalog_of_cws: serial numba kernel (40 sources) and the >1000-source parallel one (1200), with merged binaries."""
+    z = load("cw_catalog.npz")
+    locs = po.psr_locs_equatorial([{"RAJ": z["raj_hours"][i], "DECJ": z["decj_deg"][i]} for i in range(3)])
+    for a in range(3):
+        mjd = mjd_ld(z, "", a).astype(np.float64)
+        got = po.cw_catalog_dt(mjd, locs[a, 1], locs[a, 0], z[tag + "gwtheta"], z[tag + "gwphi"], z[tag + "mc"], z[tag + "dist"],
+                               z[tag + "fgw"], z[tag + "phase0"], z[tag + "psi"], z[tag + "inc"], tref=53000 * 86400, **kw)
+        assert np.all(np.isfinite(z[tag + case][a]))
+        # evolve / monochromatic are bit-identical; phase_approx differs at 3e-11 because NumPy's array pow (the stubbed
+        # numba kernel works on arrays) and scalar pow round differently and the phase subtracts two nearly equal powers
+        assert relrms(got, z[tag + case][a]) < (1e-10 if case == "approx" else 1e-13)
+
+
 def test_c3_mini_full_stack():
     z = load("c3_mini.npz")
     P = 6
