@@ -221,6 +221,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same K steps with the opt-in fp32 Gaussian transform (secondary number; `value` stays the fp64-accurate one) ----
+    _lib.call("pta_set_rng_math", 1)
+    eng.generate(R, r0=base, out=out)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.generate(R, r0=base + (W + i) * R, out=out)
+    barrier()
+    elapsed_fast = time.perf_counter() - t0
+    _lib.call("pta_set_rng_math", 0)
+    if world > 1:
+        t = torch.tensor([elapsed_fast], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_fast = float(t.item())
+
     # ---- per-kernel times of one step: HIP events on the stream the kernels are launched on ----
     kern = {}
     s = dv.stream_ptr()
@@ -321,6 +336,7 @@ def main():
         "config": {"workload": f"{args.psr} pulsars x {args.toa} TOAs synthetic array (BASELINE.json config 3 geometry): HD GWB + per-pulsar "
                                f"power-law RN (30 components) + EFAC/EQUAD + ECORR, on-chip Philox draws, {R} realisations per step per GPU",
                    "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
+        "value_fast_rng_math": world * R * K / elapsed_fast,
         "roofline": roof, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
     }
     if td is not None:

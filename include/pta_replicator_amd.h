@@ -47,6 +47,10 @@ int pta_device_info(int *cu_count, int *wavefront, char *arch, int arch_len);
  * deviate is Philox-4x32-10(key = seed, counter = (pair, stream, realisation)) + Box-Muller.
  * stream ids: (kind << 24) | pulsar, kind = 1 GWB, 2 RN, 3 WN, 4 ECORR, 5 TD.           */
 
+/* Gaussian transform used by every on-chip draw (process-wide): 0 (default) = fp64 Box-Muller with < 1 ulp log / sincos,
+ * 1 = "fast RNG math": the same uniforms through the hardware fp32 log / sqrt / sin / cos (deviates accurate to ~1e-6).  */
+int pta_set_rng_math(int fast);
+
 /* Known-answer access to the raw generator: out[i] = 4 x u32 of
  * Philox4x32-10(counter = ctr[i][0..3], key = key[0..1]).  ctr/key/out are device u32.   */
 int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int n, uint32_t *out, void *stream);
@@ -231,7 +235,8 @@ typedef struct {
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
 int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, void *stream);
 
-/* tuning knob: minimum waves per SIMD the fused kernel is compiled for (4, 6 [default] or 8) */
+/* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs per workgroup);
+ * 4 / 6 / 8 = all-VALU kernel compiled for that many waves per SIMD (kept for cross-checks)     */
 int pta_set_synth_variant(int min_waves_per_simd);
 
 int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,

@@ -59,10 +59,15 @@ def uniform_pairs(seed, realisation, stream, npairs, pair0=0):
     return u1, u2
 
 
-def normal_pairs(seed, realisation, stream, npairs, pair0=0):
+def normal_pairs(seed, realisation, stream, npairs, pair0=0, fast=False):
     """(z0[npairs], z1[npairs]): Box-Muller of the two uniforms of each Philox block.  The device evaluates
-    -2 ln u and sin/cos(2 pi u) with its own < 1 ulp kernels (pta_rng.h); libm here agrees to ~1e-16."""
+    -2 ln u and sin/cos(2 pi u) with its own < 1 ulp kernels (pta_rng.h); libm here agrees to ~1e-16.
+    fast=True mirrors the opt-in fp32 transform (hardware log/sqrt/sin/cos): agreement ~1e-6."""
     u1, u2 = uniform_pairs(seed, realisation, stream, npairs, pair0)
+    if fast:
+        rad = np.sqrt(np.float32(-1.3862943611198906) * np.log2(u1.astype(np.float32)))
+        x = np.float32(6.2831853071795864769) * u2.astype(np.float32)
+        return (rad * np.cos(x)).astype(np.float64), (rad * np.sin(x)).astype(np.float64)
     rad = np.sqrt(np.maximum(-2.0 * np.log(u1), 1e-300))
     q = np.rint(4.0 * u2)                  # exact reduction to the nearest quarter turn, like the device
     x = 6.283185307179586 * (u2 - 0.25 * q)

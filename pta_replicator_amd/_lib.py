@@ -45,6 +45,7 @@ _SIGNATURES = {
     "pta_abi_version": (c_int, []),
     "pta_last_error": (c_char_p, []),
     "pta_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
+    "pta_set_rng_math": (c_int, [c_int]),
     "pta_rng_philox_raw": (c_int, [_P, _P, c_int, _P, _P]),
     "pta_rng_fill_normal": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, _P, _P, c_int64, _P]),
     "pta_rn_basis": (c_int, [_P, c_int, c_double, _P, _P, c_int, c_int, _P, c_int64, _P]),

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
                                                                 int M, int P, int Nf, int npts, int i0,
                                                                 const double *__restrict__ pre, const double *__restrict__ FB,
                                                                 const double *__restrict__ tw, const double *__restrict__ post,
-                                                                double *__restrict__ G0, int64_t ldg) {
+                                                                double *__restrict__ G0, int64_t ldg, int fast) {
   __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
     if (t < Kf) {
       double wr, wi;
       if (RNG) {
-        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi);
+        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, fast);
       } else {
         wr = w[(int64_t)row * ldw + 2 * (t + 1)];
         wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
@@ -163,10 +163,10 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
   const int M = (int)M64;
   if (w)
     hipLaunchKernelGGL(k_gwb_czt<false>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
-                       tw, post, G0, ldg);
+                       tw, post, G0, ldg, pta_get_rng_fast());
   else
     hipLaunchKernelGGL(k_gwb_czt<true>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
-                       tw, post, G0, ldg);
+                       tw, post, G0, ldg, pta_get_rng_fast());
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

@@ -6,10 +6,11 @@
 // map) or tiny per realisation (60 RN coefficients and a 600-sample GWB row per pulsar).
 #include "pta_common.h"
 #include "pta_rng.h"
+#include "pta_mfma.h"
 
 // coef[(r*P + a)*K + c] = amp[a*K + c] * z,  z = deviate c of stream (RN, a)   (red_noise.py:126-127)
 __global__ void k_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *__restrict__ amp,
-                                 double *__restrict__ coef) {
+                                 double *__restrict__ coef, int fast) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (r, a, pair)
   int hp = K / 2;
   int total = R * P * hp;
@@ -17,7 +18,7 @@ __global__ void k_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K
   int p = idx % hp, ra = idx / hp;
   int a = ra % P, r = ra / P;
   double z0, z1;
-  pta_normal_pair(seed, r0 + (uint64_t)r, pta_stream_id(PTA_STREAM_RN, (uint32_t)a), (uint32_t)p, z0, z1);
+  pta_normal_pair(seed, r0 + (uint64_t)r, pta_stream_id(PTA_STREAM_RN, (uint32_t)a), (uint32_t)p, z0, z1, fast);
   int64_t o = (int64_t)ra * K + 2 * p;
   coef[o] = amp[(int64_t)a * K + 2 * p] * z0;
   coef[o + 1] = amp[(int64_t)a * K + 2 * p + 1] * z1;
@@ -29,7 +30,7 @@ extern "C" int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int 
   PTA_REQUIRE(R > 0 && P > 0 && K > 0 && (K % 2) == 0, PTA_E_ARG, "pta_engine_rn_coef: R=%d P=%d K=%d (K must be even)", R, P, K);
   int64_t total = (int64_t)R * P * (K / 2);
   PTA_REQUIRE(total < (1LL << 31), PTA_E_ARG, "pta_engine_rn_coef: problem too large");
-  hipLaunchKernelGGL(k_engine_rn_coef, dim3(pta_cdiv(total, 256)), dim3(256), 0, pta_stream(stream), seed, r0, R, P, K, amp, coef);
+  hipLaunchKernelGGL(k_engine_rn_coef, dim3(pta_cdiv(total, 256)), dim3(256), 0, pta_stream(stream), seed, r0, R, P, K, amp, coef, pta_get_rng_fast());
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
@@ -44,7 +45,7 @@ extern "C" int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int 
 
 template <int MINW>
 __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
-                                                                  double *__restrict__ out, int64_t ld_out) {
+                                                                  double *__restrict__ out, int64_t ld_out, int fast) {
   __shared__ double zec[ENG_RB][2 * PTA_ENGINE_EPMAX];
   // realisation groups are the FAST grid axis: the workgroups that share a tile's Ft columns / noise vectors run
   // back to back and hit L2 (with tiles fastest every sweep re-read the whole 163 MB design matrix from HBM:
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
     for (int idx = t; idx < epn * ENG_RB; idx += PTA_ENGINE_TILE) {
       int q = idx / epn, p = idx - q * epn;
       double z0, z1;
-      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)(ep0 + p), z0, z1);
+      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)(ep0 + p), z0, z1, fast);
       zec[q][2 * p] = z0;
       zec[q][2 * p + 1] = z1;
     }
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 #pragma unroll
     for (int q = 0; q < ENG_RB; ++q) {
       double z1, z2;
-      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, pair, z1, z2);
+      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, pair, z1, z2, fast);
       v[q] = v[q] + (wa * z1 + wb * z2);
     }
   }
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
     } else if (ec != 0.0) {
       const uint32_t strm = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
 #pragma unroll
-      for (int q = 0; q < ENG_RB; ++q) v[q] = v[q] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)e);
+      for (int q = 0; q < ENG_RB; ++q) v[q] = v[q] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)e, fast);
     }
   }
   const double det = pl.det ? pl.det[i] : 0.0;
@@ -134,7 +135,117 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
     if (rb + q < R) out[(int64_t)(rb + q) * ld_out + i] = v[q] + det;
 }
 
-static int g_synth_minw = 6;
+// MFMA variant (default).  The ablation of the VALU kernel above (profiles/) shows the red-noise F @ y loop as its largest
+// single term (1.5 of 4.1 ms at 68 x 5000, R = 960): 60 dependent scalar-load + FMA steps per TOA.  F @ y for a tile IS a small
+// dense product - [16 realisations x 60] . [60 x 256 TOAs] - so it goes to the otherwise idle matrix cores:
+// one wave = 16 realisations x 64 TOAs = 4 tiles of v_mfma_f64_16x16x4_f64, 15 K-steps; lane l supplies the coefficient of
+// realisation (l & 15), bin (l >> 4) and the design-matrix entry of bin (l >> 4), TOA (l & 15) of each tile, and receives the
+// sums for realisations (l >> 4) + 4 g, TOA (l & 15): exactly the (4 TOAs x 4 realisations) it then finishes on the VALU
+// (GWB interpolation, EFAC/EQUAD and ECORR deviates, deterministic term) and stores as 128-byte row segments.
+#define ENG_MR 16  // realisations per workgroup (MFMA M)
+
+__global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
+                                                                           double *__restrict__ out, int64_t ld_out, int fast) {
+  __shared__ double zec[ENG_MR][2 * PTA_ENGINE_EPMAX];
+  const int tile = blockIdx.y;
+  const int rb = blockIdx.x * ENG_MR;
+  const int a = pl.tile_psr[tile];
+  const int start = pl.tile_start[tile];
+  const int count = pl.tile_count[tile];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int P = pl.n_psr;
+  const bool has_ec = pl.ecorr_toa != nullptr;
+  const int epn = has_ec ? pl.tile_epn[tile] : 0;
+  const int ep0 = has_ec ? pl.tile_ep0[tile] : 0;
+  if (epn > 0) {
+    const uint32_t strm = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
+    for (int idx = t; idx < epn * ENG_MR; idx += PTA_ENGINE_TILE) {
+      int q = idx / epn, p = idx - q * epn;
+      double z0, z1;
+      pta_normal_pair(seed, r0 + (uint64_t)(rb + q), strm, (uint32_t)(ep0 + p), z0, z1, fast);
+      zec[q][2 * p] = z0;
+      zec[q][2 * p + 1] = z1;
+    }
+    __syncthreads();
+  }
+  const int col = l & 15, quad = l >> 4;
+  const int tbase = wv * 64 + col;  // TOA (inside the tile) of MFMA tile 0; tile j adds 16 j
+  pta_f64x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  if (pl.rn_k > 0) {
+    const int K = pl.rn_k;
+    const int ra = min(rb + col, R - 1);
+    const double *__restrict__ cf = pl.rn_coef + ((int64_t)ra * P + a) * K;
+    const double *__restrict__ Fb = pl.Ft + start;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      const int k = k0 + quad;
+      const bool kin = k < K;
+      const double av = kin ? cf[k] : 0.0;
+      double bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ti = tbase + 16 * j;
+        bv[j] = (kin && ti < count) ? Fb[(int64_t)k * pl.ldf + ti] : 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = pta_mfma_f64(av, bv[j], acc[j]);
+    }
+  }
+  const uint32_t strm_wn = pta_stream_id(PTA_STREAM_WN, (uint32_t)a);
+  const uint32_t strm_ec = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ti = tbase + 16 * j;
+    if (ti >= count) continue;
+    const int i = start + ti;
+    double v[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[g] = acc[j][g];
+    if (pl.gw_npts > 0) {  // GWB: interpolate the mixed grid series (red_noise.py:286-287)
+      const int jl = pl.gw_jlo[i];
+      const double x = pl.toa_s[i];
+      const double x0 = pl.gw_ut[jl], dx = pl.gw_ut[jl + 1] - x0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = min(rb + quad + 4 * g, R - 1);
+        const double *gp = pl.gw_G + ((int64_t)r * P + a) * pl.gw_npts;
+        double slope = (gp[jl + 1] - gp[jl]) / dx;
+        v[g] = v[g] + (slope * (x - x0) + gp[jl]);
+      }
+    }
+    if (pl.wn_a) {  // EFAC/EQUAD (white_noise.py:105-109)
+      const double wa = pl.wn_a[i], wb = pl.wn_b[i];
+      const uint32_t pair = (uint32_t)pl.idx_in_psr[i];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        double z1, z2;
+        pta_normal_pair(seed, r0 + (uint64_t)(rb + quad + 4 * g), strm_wn, pair, z1, z2, fast);
+        v[g] = v[g] + (wa * z1 + wb * z2);
+      }
+    }
+    if (has_ec) {  // ECORR (white_noise.py:182)
+      const double ec = pl.ecorr_toa[i];
+      const int e = pl.epoch_of[i];
+      if (epn > 0) {
+        const int o = e - 2 * ep0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * zec[quad + 4 * g][o];
+      } else if (ec != 0.0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + quad + 4 * g), strm_ec, (uint32_t)e, fast);
+      }
+    }
+    const double det = pl.det ? pl.det[i] : 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = rb + quad + 4 * g;
+      if (r < R) out[(int64_t)r * ld_out + i] = v[g] + det;
+    }
+  }
+}
+
+static int g_synth_minw = 0;  // 0 = MFMA variant (default); 4 / 6 / 8 = VALU variant compiled for that many waves per SIMD
 extern "C" int pta_set_synth_variant(int minw) {
   g_synth_minw = minw;
   return PTA_OK;
@@ -154,15 +265,21 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
   PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed one launch", p.n_tiles);
+  if (g_synth_minw == 0) {
+    hipLaunchKernelGGL(k_engine_synth_mfma, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R,
+                       out, ld_out, pta_get_rng_fast());
+    PTA_LAUNCH_CHECK();
+    return PTA_OK;
+  }
   dim3 g(pta_cdiv(R, ENG_RB), p.n_tiles), b(PTA_ENGINE_TILE);
   // register budget per lane (waves per SIMD the compiler must allow): the kernel alternates long Box-Muller chains
   // with a load-fed FMA loop, so occupancy matters more than keeping all eight chains' temporaries in registers
   if (g_synth_minw >= 8)
-    hipLaunchKernelGGL(k_engine_synth<8>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
+    hipLaunchKernelGGL(k_engine_synth<8>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
   else if (g_synth_minw >= 6)
-    hipLaunchKernelGGL(k_engine_synth<6>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
+    hipLaunchKernelGGL(k_engine_synth<6>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
   else
-    hipLaunchKernelGGL(k_engine_synth<4>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out);
+    hipLaunchKernelGGL(k_engine_synth<4>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

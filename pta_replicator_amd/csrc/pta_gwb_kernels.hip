@@ -137,7 +137,7 @@ template <int NT, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_gwb_idft_sym_rng(uint64_t seed, uint64_t r0, int M, int P, int Nf,
                                                                 const double *__restrict__ Tsym,
                                                                 const double *__restrict__ rot, int npts,
-                                                                double *__restrict__ G0, int64_t ldg) {
+                                                                double *__restrict__ G0, int64_t ldg, int fast) {
   using C = pta_sym_cfg<NT>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 x SLAB_PAD
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, MINW) void k_gwb_idft_sym_rng(uint64_t seed, u
 #pragma unroll
     for (int q = 0; q < C::NLD; ++q) regs[q] = src[(int64_t)ksn * (C::SLAB_PAD / 2) + q * 256];
     double re, im;
-    pta_normal_pair(seed, real, strm, (uint32_t)(ks * 4 + kk + 1), re, im);  // pair k <-> w[a,k] (red_noise.py:240)
+    pta_normal_pair(seed, real, strm, (uint32_t)(ks * 4 + kk + 1), re, im, fast);  // pair k <-> w[a,k] (red_noise.py:240)
     const double2 cs = reinterpret_cast<const double2 *>(rot)[ks * 4 + kk];
     const double ar = re * cs.x - im * cs.y;  // rotated draw
     const double br = re * cs.y + im * cs.x;
@@ -256,15 +256,15 @@ extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf
   if (nt == 19) {
     auto kern = k_gwb_idft_sym_rng<19, 1>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
   } else if (nt == 10) {
     auto kern = k_gwb_idft_sym_rng<10, 2>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
   } else {
     auto kern = k_gwb_idft_sym_rng<7, 2>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg);
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
   }
   PTA_LAUNCH_CHECK();
   return PTA_OK;

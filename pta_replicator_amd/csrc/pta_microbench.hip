@@ -47,12 +47,12 @@ __global__ void k_mb_copy(const double2 *__restrict__ in, double2 *__restrict__ 
   for (; i < n2; i += stride) out[i] = in[i];
 }
 
-__global__ __launch_bounds__(256) void k_mb_rng(double *out, int iters) {
+__global__ __launch_bounds__(256) void k_mb_rng(double *out, int iters, int fast) {
   double s = 0.0;
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   for (int it = 0; it < iters; ++it) {
     double z0, z1;
-    pta_normal_pair(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p, z0, z1);
+    pta_normal_pair(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p, z0, z1, fast);
     s += z0 * z1;
   }
   if (s == 123.456) out[0] = s;
@@ -99,7 +99,7 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result
           work = 2.0 * (double)nbytes * reps;
           break;
         case 4:
-          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, pta_get_rng_fast());
           work = (double)cus * bpc * 256 * iters * 2.0 * reps;  // normals
           break;
         default:

@@ -173,10 +173,28 @@ PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
   cs = (k == 1 || k == 2) ? -c1 : c1;
 }
 
-// Box-Muller: (z0, z1) iid N(0,1)
-PTA_HD void pta_normal_pair(uint64_t seed, uint64_t realisation, uint32_t stream, uint32_t pair, double &z0, double &z1) {
+// Box-Muller: (z0, z1) iid N(0,1).
+// fast = 0 (default): fp64 transform, every step < 1 ulp (the deviates are reproducible on the host to ~1e-16).
+// fast = 1 ("fast RNG math", opt-in): the SAME uniforms through the hardware fp32 transcendentals (v_log_f32, v_sqrt_f32,
+//           v_sin_f32 / v_cos_f32, which take their argument in turns) - deviates accurate to ~1e-6, a statistically
+//           irrelevant perturbation of a random number, at 40 % of the instructions.  Signal arithmetic stays fp64.
+PTA_HD void pta_normal_pair(uint64_t seed, uint64_t realisation, uint32_t stream, uint32_t pair, double &z0, double &z1, int fast = 0) {
   double u1, u2, s, c;
   pta_uniform_pair(pta_philox_draw(seed, realisation, stream, pair), u1, u2);
+  if (fast) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf((float)u1));  // sqrt(-2 ln2 log2 u1)
+    float x = (float)u2;
+    z0 = (double)(rad * __builtin_amdgcn_cosf(x));
+    z1 = (double)(rad * __builtin_amdgcn_sinf(x));
+#else
+    float rad = sqrtf(-1.3862943611198906f * log2f((float)u1));
+    float x = 6.2831853071795864769f * (float)u2;
+    z0 = (double)(rad * cosf(x));
+    z1 = (double)(rad * sinf(x));
+#endif
+    return;
+  }
   double rad = pta_sqrt_pos(pta_neg2log(u1));
   pta_sincos_2pi(u2, s, c);
   z0 = rad * c;
@@ -184,8 +202,8 @@ PTA_HD void pta_normal_pair(uint64_t seed, uint64_t realisation, uint32_t stream
 }
 
 // single deviate with index e of a stream: pair e>>1, branch e&1
-PTA_HD double pta_normal_single(uint64_t seed, uint64_t realisation, uint32_t stream, uint32_t e) {
+PTA_HD double pta_normal_single(uint64_t seed, uint64_t realisation, uint32_t stream, uint32_t e, int fast = 0) {
   double z0, z1;
-  pta_normal_pair(seed, realisation, stream, e >> 1, z0, z1);
+  pta_normal_pair(seed, realisation, stream, e >> 1, z0, z1, fast);
   return (e & 1u) ? z1 : z0;
 }

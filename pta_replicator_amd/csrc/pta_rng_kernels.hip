@@ -23,12 +23,12 @@ extern "C" int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int 
 }
 
 __global__ void k_fill_normal(uint64_t seed, uint64_t r0, uint32_t stream_id, int npairs, int interleave,
-                              double *__restrict__ z0, double *__restrict__ z1, int64_t ld) {
+                              double *__restrict__ z0, double *__restrict__ z1, int64_t ld, int fast) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
   if (p >= npairs) return;
   double a, b;
-  pta_normal_pair(seed, r0 + (uint64_t)r, stream_id, (uint32_t)p, a, b);
+  pta_normal_pair(seed, r0 + (uint64_t)r, stream_id, (uint32_t)p, a, b, fast);
   if (interleave) {
     double2 v = make_double2(a, b);
     *reinterpret_cast<double2 *>(z0 + (int64_t)r * ld + 2 * (int64_t)p) = v;
@@ -46,7 +46,7 @@ extern "C" int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t s
   PTA_REQUIRE(!interleave || (ld % 2 == 0 && ((uintptr_t)z0 % 16) == 0), PTA_E_ARG,
               "pta_rng_fill_normal: interleaved output needs even ld and 16-byte alignment");
   hipLaunchKernelGGL(k_fill_normal, dim3(pta_cdiv(npairs, 256), R), dim3(256), 0, pta_stream(stream), seed, r0, stream_id,
-                     npairs, interleave, z0, z1, ld);
+                     npairs, interleave, z0, z1, ld, pta_get_rng_fast());
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

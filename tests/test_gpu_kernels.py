@@ -60,6 +60,25 @@ def test_rng_fill_matches_numpy_twin(gpu, interleave):
         assert np.max(np.abs(got0[r] - e0)) < 1e-13 and np.max(np.abs(got1[r] - e1)) < 1e-13
 
 
+def test_fast_rng_math_mode(gpu):
+    """opt-in fp32-transcendental Gaussian transform: same uniforms, deviates within ~1e-6 of the fp64 ones, unit variance."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    seed, npairs = 4242, 200000
+    sid = philox_ref.stream_id(philox_ref.STREAM_WN, 3)
+    acc, fast = dv.empty((2 * npairs,)), dv.empty((2 * npairs,))
+    lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(acc), None, 2 * npairs, gpu["s"])
+    lib.call("pta_set_rng_math", 1)
+    try:
+        lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(fast), None, 2 * npairs, gpu["s"])
+    finally:
+        lib.call("pta_set_rng_math", 0)
+    a, f = acc.cpu().numpy(), fast.cpu().numpy()
+    assert np.max(np.abs(a - f)) < 2e-5 and np.sqrt(np.mean((a - f) ** 2)) < 2e-6
+    z0, z1 = philox_ref.normal_pairs(seed, 9, sid, npairs, fast=True)
+    assert np.max(np.abs(f[0::2] - z0)) < 2e-5 and np.max(np.abs(f[1::2] - z1)) < 2e-5
+    assert abs(f.var() - 1) < 5 * np.sqrt(2 / f.size) and abs(np.mean(f ** 4) - 3) < 5 * np.sqrt(96 / f.size)
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (70, 130, 37), (200, 600, 301), (3, 600, 2998), (300, 257, 75), (515, 400, 64)])
 @pytest.mark.parametrize("transB", [0, 1])
 def test_dgemm_mfma_and_valu(gpu, shape, transB):
