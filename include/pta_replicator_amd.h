@@ -159,6 +159,7 @@ int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const dou
  * pta_gwb_czt: w == NULL draws on chip (stream (GWB, a), pair k, like pta_gwb_idft_rng), else w[R*P x ldw]
  * interleaved (re, im) rows as in pta_gwb_idft.                                              */
 int pta_gwb_czt_fits(int Nf, int npts, int i0);
+int pta_set_czt_variant(int variant); /* 0 (default): one workgroup barrier per FFT pass; 1: fused wave-local pass pairs */
 int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *pre, double *FB, double *tw,
                       double *post, void *stream);
 int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,

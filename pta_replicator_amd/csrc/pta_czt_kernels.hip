@@ -85,8 +85,107 @@ extern "C" int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, 
 
 extern "C" int pta_gwb_czt_fits(int Nf, int npts, int i0) { return czt_fits(Nf, npts, i0) ? 1 : 0; }
 
-template <bool RNG>
+// order LDS traffic of one wave without a workgroup barrier (the hardware executes a wave's LDS instructions in order;
+// this only stops the compiler from moving accesses across the hand-over point)
+__device__ __forceinline__ void pta_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// QA = number of 512-strided input elements per first-pass butterfly that can be non-zero (ceil(Kf / 512)): 6 at the
+// headline Nf; known at compile time so that the draw chains are straight-line code with all loads hoisted
+template <bool RNG, int QA>
 __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
+                                                                int M, int P, int Nf, int npts, int i0,
+                                                                const double *__restrict__ pre, const double *__restrict__ FB,
+                                                                const double *__restrict__ tw, const double *__restrict__ post,
+                                                                double *__restrict__ G0, int64_t ldg, int fast) {
+  __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const int Kf = Nf - 2;
+  const uint64_t real = r0 + (uint64_t)(row / P);
+  const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(row % P));
+  pta_cplx v[8], tv[8];
+  int b, o;
+
+  // ---- forward, column pair.  The s = 512 butterfly starts from registers: element o + 512 q is the chirped,
+  // spectrum-weighted draw A[t] = w[a, t+1] * pre[t] (pair k = t+1 <-> Re, Im of w[a,k], red_noise.py:240), zero for t >= Kf
+  pta_fft_map<9>(tid, b, o);
+  pta_fft_twiddles<9>(tw, o, tv);
+  {
+    const pta_cplx *pre2 = reinterpret_cast<const pta_cplx *>(pre);
+    pta_cplx pc[QA];
+#pragma unroll
+    for (int q = 0; q < QA; ++q) pc[q] = pre2[min(o + 512 * q, Kf - 1)];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q < QA) {
+        const int t = min(o + 512 * q, Kf - 1);
+        double wr, wi;
+        if (RNG) {
+          pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, fast);
+        } else {
+          wr = w[(int64_t)row * ldw + 2 * (t + 1)];
+          wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
+        }
+        const bool on = (o + 512 * q) < Kf;
+        v[q] = {on ? wr * pc[q].re - wi * pc[q].im : 0.0, on ? wr * pc[q].im + wi * pc[q].re : 0.0};
+      } else {
+        v[q] = {0.0, 0.0};
+      }
+    }
+  }
+  pta_fft_core<false, 9>(v, tv);
+  pta_fft_store<9>(re, im, b, o, v);
+  pta_wave_sync();
+  pta_fft_pass<false, 6>(re, im, tw, tid);
+  __syncthreads();
+  // ---- forward, block pair; the s = 1 butterfly stays in registers through the product with the chirp spectrum (both in
+  // digit-reversed order) and the first inverse butterfly
+  pta_fft_pass<false, 3>(re, im, tw, tid);
+  pta_wave_sync();
+  pta_fft_map<0>(tid, b, o);
+  {
+    const pta_cplx *fb = reinterpret_cast<const pta_cplx *>(FB) + 8 * b;
+    pta_cplx fv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) fv[q] = fb[q];
+    pta_fft_load<0>(re, im, b, o, v);
+    pta_dft8<false>(v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = pta_cmul(v[q], fv[q]);
+    pta_dft8<true>(v);
+  }
+  pta_fft_store<0>(re, im, b, o, v);
+  pta_wave_sync();
+  pta_fft_pass<true, 3>(re, im, tw, tid);
+  __syncthreads();
+  // ---- inverse, column pair; the last butterfly's outputs o + 512 q go straight to memory: x_j = Re(post_j * y_j) with
+  // y_j at circular index j - 1, so only indices i0-1 .. i0+npts-2 are stored
+  pta_fft_pass<true, 6>(re, im, tw, tid);
+  pta_wave_sync();
+  pta_fft_map<9>(tid, b, o);
+  pta_fft_twiddles<9>(tw, o, tv);
+  pta_fft_load<9>(re, im, b, o, v);
+  pta_fft_core<true, 9>(v, tv);
+  const pta_cplx *post2 = reinterpret_cast<const pta_cplx *>(post);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int jj = o + 512 * q - (i0 - 1);
+    if (jj >= 0 && jj < npts) {
+      const pta_cplx pp = post2[jj];
+      G0[(int64_t)row * ldg + jj] = v[q].re * pp.re - v[q].im * pp.im;
+    }
+  }
+}
+
+// Reference structure of the same transform: every pass separated by a workgroup barrier, the draws staged through LDS,
+// the chirp-spectrum product and the output as separate sweeps.  Kept because it is the faster one on MI355X
+//  and as a cross-check of the fused variant.
+template <bool RNG>
+__global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt_simple(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
                                                                 int M, int P, int Nf, int npts, int i0,
                                                                 const double *__restrict__ pre, const double *__restrict__ FB,
                                                                 const double *__restrict__ tw, const double *__restrict__ post,
@@ -150,6 +249,12 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
   }
 }
 
+static int g_czt_variant = 0;  // 0 = barrier-per-pass kernel (default, faster), 1 = fused wave-local variant
+extern "C" int pta_set_czt_variant(int v) {
+  g_czt_variant = v;
+  return PTA_OK;
+}
+
 // w == NULL: draws generated on chip (throughput mode); else w[M x ldw] interleaved (re, im) rows (replay mode)
 extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
                            const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
@@ -161,12 +266,27 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
   int64_t M64 = (int64_t)R * P;
   PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_czt: R*P too large");
   const int M = (int)M64;
-  if (w)
-    hipLaunchKernelGGL(k_gwb_czt<false>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
-                       tw, post, G0, ldg, pta_get_rng_fast());
-  else
-    hipLaunchKernelGGL(k_gwb_czt<true>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, pre, FB,
-                       tw, post, G0, ldg, pta_get_rng_fast());
+  const int fastm = pta_get_rng_fast();
+  if (g_czt_variant == 0) {
+    if (w)
+      hipLaunchKernelGGL(k_gwb_czt_simple<false>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0,
+                         pre, FB, tw, post, G0, ldg, fastm);
+    else
+      hipLaunchKernelGGL(k_gwb_czt_simple<true>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0,
+                         pre, FB, tw, post, G0, ldg, fastm);
+    PTA_LAUNCH_CHECK();
+    return PTA_OK;
+  }
+  const bool q6 = (Nf - 2) <= 6 * 512;
+#define PTA_CZT_LAUNCH(RNGV, QAV)                                                                                                  \
+  hipLaunchKernelGGL((k_gwb_czt<RNGV, QAV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, \
+                     pre, FB, tw, post, G0, ldg, fastm)
+  if (w) {
+    if (q6) PTA_CZT_LAUNCH(false, 6); else PTA_CZT_LAUNCH(false, 8);
+  } else {
+    if (q6) PTA_CZT_LAUNCH(true, 6); else PTA_CZT_LAUNCH(true, 8);
+  }
+#undef PTA_CZT_LAUNCH
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

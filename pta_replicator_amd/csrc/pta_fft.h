@@ -8,16 +8,23 @@
 // ~0.5 MFLOP per row on the VALU instead of 3.6 MFLOP of dense DFT on the matrix cores.
 //
 // Forward = decimation in frequency (natural in, digit-reversed out), inverse = decimation in time (digit-reversed
-// in, natural out): the pointwise product happens in digit-reversed order, so no reordering pass exists.  All code
-// is per-"thread" work between barriers, __host__ __device__, so tests/hostcheck can run it on the CPU.
+// in, natural out): the pointwise product happens in digit-reversed order, so no reordering pass exists.
+//
+// Work distribution (512 threads = 8 waves, one radix-8 butterfly per thread per pass).  4096 = 64 x 64: the two
+// long-stride passes (s = 512, 64) only mix the 64 elements of a "column" {o + 64 m}, the two short-stride passes
+// (s = 8, 1) only the 64 elements of a contiguous block.  Wave w owns columns 8w..8w+7 in the first pair and blocks
+// 8w..8w+7 in the second, so inside a pair the hand-over is WAVE-local (LDS ops of one wave execute in order - no
+// workgroup barrier); only the column <-> block transposition between the pairs needs __syncthreads().
+// All code is per-"thread" work, __host__ __device__, so tests/hostcheck can run it on the CPU.
 #pragma once
 #include "pta_rng.h"  // PTA_HD
 
 #define PTA_FFT_N 4096
-#define PTA_FFT_THREADS 512  // one radix-8 butterfly per thread per pass: 16 waves per CU with two rows resident
-// physical LDS index of logical element i: one pad double per 8 keeps every pass's 8-strided accesses conflict free
-#define PTA_FFT_PHYS(i) ((i) + ((i) >> 3))
-#define PTA_FFT_PLANE (PTA_FFT_N + PTA_FFT_N / 8)  // doubles per plane (re or im)
+#define PTA_FFT_THREADS 512
+// physical LDS index of logical element i: one pad double per 8 elements and eight more per 512 keep the 8-strided
+// accesses of every pass, under the wave <-> column/block mapping above, on distinct banks
+#define PTA_FFT_PHYS(i) ((i) + ((i) >> 3) + (((i) >> 9) << 3))
+#define PTA_FFT_PLANE (PTA_FFT_N + PTA_FFT_N / 8 + 64)  // doubles per plane (re or im)
 
 struct pta_cplx {
   double re, im;
@@ -57,43 +64,90 @@ PTA_HD void pta_dft8(pta_cplx *v) {
   v[7] = pta_csub(d2, d3);
 }
 
-// One radix-8 pass for one thread (512 butterflies per pass over NT threads).  LOG2S in {9, 6, 3, 0} (stride s = 512,
-// 64, 8, 1).  tw[m] = e^{-2 pi i m / 4096} (re, im interleaved).
+// Stride of a pass: LOG2S in {9, 6, 3, 0} (s = 512, 64, 8, 1).  Butterfly (b, o), o < s, touches logical elements
+// b*8s + o + q*s, q = 0..7, which sit at constant physical distances QSTEP (every q*s is a multiple of 8 for s >= 8
+// and never crosses a 512 boundary for s < 512; for s = 1 the eight elements are contiguous).
+template <int LOG2S>
+struct pta_fft_stride {
+  static constexpr int S = 1 << LOG2S;
+  static constexpr int QSTEP = (LOG2S == 9) ? 512 + 64 + 8 : (LOG2S >= 3 ? S + (S >> 3) : 1);
+  static constexpr int TSTEP = 512 >> LOG2S;  // 4096 / (8 s)
+};
+
+template <int LOG2S>
+PTA_HD int pta_fft_base(int b, int o) {  // logical index of element q = 0
+  return (b << (LOG2S + 3)) + o;
+}
+
+// (b, o) of the butterfly thread `tid` executes in each pass (wave w = tid >> 6, lane l = tid & 63)
+template <int LOG2S>
+PTA_HD void pta_fft_map(int tid, int &b, int &o) {
+  const int w = tid >> 6, l = tid & 63;
+  if (LOG2S == 9) {         // s = 512: column 8w + (l & 7), row group l >> 3
+    b = 0;
+    o = 8 * w + (l & 7) + 64 * (l >> 3);
+  } else if (LOG2S == 6) {  // s = 64: 512-block l >> 3, column 8w + (l & 7)
+    b = l >> 3;
+    o = 8 * w + (l & 7);
+  } else if (LOG2S == 3) {  // s = 8: 64-block 8w + (l >> 3), offset l & 7
+    b = 8 * w + (l >> 3);
+    o = l & 7;
+  } else {                  // s = 1: butterfly = tid
+    b = tid;
+    o = 0;
+  }
+}
+
+template <int LOG2S>
+PTA_HD void pta_fft_load(const double *re, const double *im, int b, int o, pta_cplx *v) {
+  const int p0 = PTA_FFT_PHYS(pta_fft_base<LOG2S>(b, o));
+#pragma unroll
+  for (int q = 0; q < 8; ++q) v[q] = {re[p0 + q * pta_fft_stride<LOG2S>::QSTEP], im[p0 + q * pta_fft_stride<LOG2S>::QSTEP]};
+}
+
+template <int LOG2S>
+PTA_HD void pta_fft_store(double *re, double *im, int b, int o, const pta_cplx *v) {
+  const int p0 = PTA_FFT_PHYS(pta_fft_base<LOG2S>(b, o));
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    re[p0 + q * pta_fft_stride<LOG2S>::QSTEP] = v[q].re;
+    im[p0 + q * pta_fft_stride<LOG2S>::QSTEP] = v[q].im;
+  }
+}
+
+// the twiddles of one butterfly, fetched up front so that the loads are in flight while the LDS reads / the RNG run
+template <int LOG2S>
+PTA_HD void pta_fft_twiddles(const double *tw, int o, pta_cplx *w) {
+  const pta_cplx *tw2 = reinterpret_cast<const pta_cplx *>(tw);
+  const int m1 = o * pta_fft_stride<LOG2S>::TSTEP;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) w[q] = (LOG2S > 0) ? tw2[q * m1] : pta_cplx{1.0, 0.0};
+}
+
+// the arithmetic of one butterfly, in registers.  w[q] = e^{-2 pi i o q / (8 s)} from pta_fft_twiddles.
 //   forward (DIF): butterfly, then output q times W^{o q}          passes in order s = 512, 64, 8, 1
 //   inverse (DIT): input q times conj(W)^{o q}, then butterfly     passes in order s = 1, 8, 64, 512
-// The eight elements of a butterfly sit at constant physical distances (s + s/8 for s >= 8 because q*s is a multiple
-// of 8; 1 for s = 1 where base = 8 beta -> 9 beta), so every LDS access is base register + immediate offset.
-template <bool INV, int LOG2S, int NT = PTA_FFT_THREADS>
-PTA_HD void pta_fft_pass(double *re, double *im, const double *tw, int tid) {
-  constexpr int S = 1 << LOG2S;
-  constexpr int QSTEP = (LOG2S >= 3) ? S + (S >> 3) : 1;
-  constexpr int TSTEP = 512 >> LOG2S;  // 4096 / (8 s)
-  const pta_cplx *tw2 = reinterpret_cast<const pta_cplx *>(tw);
+template <bool INV, int LOG2S>
+PTA_HD void pta_fft_core(pta_cplx *v, const pta_cplx *w) {
+  if (INV && LOG2S > 0) {
 #pragma unroll
-  for (int h = 0; h < 512 / NT; ++h) {
-    const int beta = tid + NT * h;
-    const int b = beta >> LOG2S, o = beta & (S - 1);
-    const int p0 = PTA_FFT_PHYS((b << (LOG2S + 3)) + o);
-    pta_cplx v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = {re[p0 + q * QSTEP], im[p0 + q * QSTEP]};
-    const int m1 = o * TSTEP;
-    if (INV && LOG2S > 0) {
-#pragma unroll
-      for (int q = 1; q < 8; ++q) {
-        pta_cplx w = tw2[q * m1];
-        v[q] = pta_cmul(v[q], pta_cplx{w.re, -w.im});
-      }
-    }
-    pta_dft8<INV>(v);
-    if (!INV && LOG2S > 0) {
-#pragma unroll
-      for (int q = 1; q < 8; ++q) v[q] = pta_cmul(v[q], tw2[q * m1]);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      re[p0 + q * QSTEP] = v[q].re;
-      im[p0 + q * QSTEP] = v[q].im;
-    }
+    for (int q = 1; q < 8; ++q) v[q] = pta_cmul(v[q], pta_cplx{w[q].re, -w[q].im});
   }
+  pta_dft8<INV>(v);
+  if (!INV && LOG2S > 0) {
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v[q] = pta_cmul(v[q], w[q]);
+  }
+}
+
+// load - butterfly - store of one pass for one thread
+template <bool INV, int LOG2S>
+PTA_HD void pta_fft_pass(double *re, double *im, const double *tw, int tid) {
+  int b, o;
+  pta_fft_map<LOG2S>(tid, b, o);
+  pta_cplx v[8], w[8];
+  pta_fft_twiddles<LOG2S>(tw, o, w);
+  pta_fft_load<LOG2S>(re, im, b, o, v);
+  pta_fft_core<INV, LOG2S>(v, w);
+  pta_fft_store<LOG2S>(re, im, b, o, v);
 }

@@ -16,6 +16,10 @@ def timed(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 res = ctypes.c_double(0)
+for cv in (0, 1):
+    _lib.call("pta_set_czt_variant", cv)
+    print(json.dumps({"czt_variant": cv, "ms": round(timed(lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, s)), 3)}))
+_lib.call("pta_set_czt_variant", 0)
 for var in (0, 6):
     _lib.call("pta_set_synth_variant", var)
     print(json.dumps({"synth_variant": var, "ms": round(timed(lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(outb), outb.stride(0), s)), 3)}))

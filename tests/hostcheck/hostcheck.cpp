@@ -6,6 +6,18 @@
 #include "../../pta_replicator_amd/csrc/pta_orf.h"
 #include "../../pta_replicator_amd/csrc/pta_fft.h"
 
+// FFT passes with the 512 "threads" of a workgroup emulated.  The kernel only puts a workgroup barrier between the
+// column pair (s = 512, 64) and the block pair (s = 8, 1); inside a pair a wave runs both passes back to back.  The
+// emulation therefore executes WAVE by WAVE (all lanes of pass 1, then all lanes of pass 2, then the next wave): if a
+// pass needed data of another wave, this order would expose it.
+template <bool INV, int L1, int L2>
+static void hc_pair(double *re, double *im, const double *tw) {
+  for (int w = 0; w < PTA_FFT_THREADS / 64; ++w) {
+    for (int l = 0; l < 64; ++l) pta_fft_pass<INV, L1>(re, im, tw, 64 * w + l);
+    for (int l = 0; l < 64; ++l) pta_fft_pass<INV, L2>(re, im, tw, 64 * w + l);
+  }
+}
+
 extern "C" {
 
 void hc_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
@@ -43,19 +55,13 @@ void hc_orf_basis(const double *locs, int P, int lmax, double *basis) {
       }
 }
 
-// FFT passes with the 256 "threads" of a workgroup emulated sequentially; a barrier = the end of a tid loop.
-// re/im are PTA_FFT_PLANE-sized planes addressed through PTA_FFT_PHYS.
 void hc_fft_forward(double *re, double *im, const double *tw) {
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 9>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 6>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 3>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<false, 0>(re, im, tw, tid);
+  hc_pair<false, 9, 6>(re, im, tw);
+  hc_pair<false, 3, 0>(re, im, tw);
 }
 void hc_fft_inverse(double *re, double *im, const double *tw) {
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 0>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 3>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 6>(re, im, tw, tid);
-  for (int tid = 0; tid < PTA_FFT_THREADS; ++tid) pta_fft_pass<true, 9>(re, im, tw, tid);
+  hc_pair<true, 0, 3>(re, im, tw);
+  hc_pair<true, 6, 9>(re, im, tw);
 }
 int hc_fft_phys(int i) { return PTA_FFT_PHYS(i); }
 int hc_fft_plane() { return PTA_FFT_PLANE; }

@@ -222,12 +222,14 @@ def test_gwb_idft_rng_equals_replay_of_its_draws(gpu, variant, Nf, npts):
     assert np.max(np.abs(wr[0::2] - z0)) < 1e-13 and np.max(np.abs(wr[1::2] - z1)) < 1e-13
 
 
-@pytest.mark.parametrize("Nf,npts", [(3000, 600), (3001, 600), (601, 200), (500, 37), (2400, 601)])
-def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("Nf,npts", [(3000, 600), (3001, 600), (601, 200), (500, 37), (2400, 601), (3400, 600)])
+def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts, variant):
     """chirp-z path: (a) replay form vs numpy's Hermitian-packed ifft; (b) on-chip-RNG form vs the DFT-GEMM over the
     dumped draws."""
     dv, lib = gpu["dv"], gpu["lib"]
     assert lib.lib.pta_gwb_czt_fits(Nf, npts, 10) == 1 and lib.lib.pta_gwb_czt_fits(5000, 1000, 10) == 0
+    lib.call("pta_set_czt_variant", variant)
     rng = np.random.default_rng(Nf)
     seed, r0, R, P = 99, 12345, 2, 3
     M = R * P
@@ -258,6 +260,7 @@ def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts):
     G_rep = dv.zeros((M, npts))
     lib.call("pta_gwb_idft", dv.ptr(wd), 2 * Nf, M, Nf, dv.ptr(T), ldt, npts, dv.ptr(G_rep), npts, 1, gpu["s"])
     a_, b_ = G_rng.cpu().numpy(), G_rep.cpu().numpy()
+    lib.call("pta_set_czt_variant", 0)
     assert np.max(np.abs(a_ - b_)) < 1e-12 * np.max(np.abs(b_))
 
 
