@@ -455,6 +455,19 @@ class ReplicaEngine:
             return sig
         return total
 
+    def inject(self, r, signal_name="engine_realisation"):
+        """Write realisation r into the pulsar objects the way the reference's add_* functions do - record the delay in
+        ``added_signals`` / ``added_signals_time``, shift the TOAs, rebuild the residuals - but ONCE per pulsar with the summed
+        delay (the PINT sink dominates real runs, so it is paid once, not once per signal)."""
+        from ._compat import TimeDelta, u
+        row = self.generate(1, r0=r)[0].cpu().numpy()
+        for a, psr in enumerate(self.psrs):
+            dt = row[self.off[a]:self.off[a + 1]] * u.s
+            psr.update_added_signals("{}_{}".format(psr.name, signal_name), {"seed": self.seed, "realisation": int(r)}, dt)
+            psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
+            psr.update_residuals()
+        return row
+
     def split(self, arr):
         """per-pulsar views of an [..., n_toa] array."""
         return [arr[..., self.off[a]:self.off[a + 1]] for a in range(self.P)]
