@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure (not in the local guide)
 # HBM bytes per launch from the PMC passes of the same command (scripts/gpu_profile.sh -> profiles/), KiB as rocprofv3 reports them;
 # FETCH_SIZE is uncorrected (MI355X_MICROARCH.md: it under-counts wide streaming reads by up to 2x on gfx950)
-PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 882708.0, "write_kib": 2550930.0,
-                                    "source": "profiles/r01_rocprofv3_summary_run19.txt"}}
+PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 969897.0, "write_kib": 2696790.0,
+                                    "source": "profiles/r01_rocprofv3_summary_run37.txt"}}
 
 
 def headline_array(P=68, N=5000, seed=68):

@@ -184,12 +184,13 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
 // Reference structure of the same transform: every pass separated by a workgroup barrier, the draws staged through LDS,
 // the chirp-spectrum product and the output as separate sweeps.  Kept because it is the faster one on MI355X
 //  and as a cross-check of the fused variant.
-template <bool RNG>
+// FAST (the opt-in fp32 Box-Muller transcendentals, pta_set_rng_math) is a template parameter: separate kernel names in profiles
+template <bool RNG, bool FAST>
 __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt_simple(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
                                                                 int M, int P, int Nf, int npts, int i0,
                                                                 const double *__restrict__ pre, const double *__restrict__ FB,
                                                                 const double *__restrict__ tw, const double *__restrict__ post,
-                                                                double *__restrict__ G0, int64_t ldg, int fast) {
+                                                                double *__restrict__ G0, int64_t ldg) {
   __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt_simple(uint64_t 
     if (t < Kf) {
       double wr, wi;
       if (RNG) {
-        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, fast);
+        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, FAST ? 1 : 0);
       } else {
         wr = w[(int64_t)row * ldw + 2 * (t + 1)];
         wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
@@ -268,12 +269,16 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
   const int M = (int)M64;
   const int fastm = pta_get_rng_fast();
   if (g_czt_variant == 0) {
+#define PTA_CZT_SIMPLE(RNGV, FASTV)                                                                                                       \
+  hipLaunchKernelGGL((k_gwb_czt_simple<RNGV, FASTV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, \
+                     npts, i0, pre, FB, tw, post, G0, ldg)
     if (w)
-      hipLaunchKernelGGL(k_gwb_czt_simple<false>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0,
-                         pre, FB, tw, post, G0, ldg, fastm);
+      PTA_CZT_SIMPLE(false, false);
+    else if (fastm)
+      PTA_CZT_SIMPLE(true, true);
     else
-      hipLaunchKernelGGL(k_gwb_czt_simple<true>, dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0,
-                         pre, FB, tw, post, G0, ldg, fastm);
+      PTA_CZT_SIMPLE(true, false);
+#undef PTA_CZT_SIMPLE
     PTA_LAUNCH_CHECK();
     return PTA_OK;
   }

@@ -144,8 +144,10 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 // (GWB interpolation, EFAC/EQUAD and ECORR deviates, deterministic term) and stores as 128-byte row segments.
 #define ENG_MR 16  // realisations per workgroup (MFMA M)
 
+template <bool FAST>
 __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
-                                                                           double *__restrict__ out, int64_t ld_out, int fast) {
+                                                                           double *__restrict__ out, int64_t ld_out) {
+  constexpr int fast = FAST ? 1 : 0;  // template parameter: the two RNG-math modes are separate kernels (and profile rows)
   __shared__ double zec[ENG_MR][2 * PTA_ENGINE_EPMAX];
   const int tile = blockIdx.y;
   const int rb = blockIdx.x * ENG_MR;
@@ -266,8 +268,12 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
   PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed one launch", p.n_tiles);
   if (g_synth_minw == 0) {
-    hipLaunchKernelGGL(k_engine_synth_mfma, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R,
-                       out, ld_out, pta_get_rng_fast());
+    if (pta_get_rng_fast())
+      hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed,
+                         r0, R, out, ld_out);
+    else
+      hipLaunchKernelGGL(k_engine_synth_mfma<false>, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed,
+                         r0, R, out, ld_out);
     PTA_LAUNCH_CHECK();
     return PTA_OK;
   }
