@@ -24,6 +24,8 @@ variants.npz     the branches the shipped vector does not pin: t
                  default RN convention, every add_cgw branch.
 c3_mini.npz      a 6-pulsar miniature of config 3 (HD GWB + RN + EFAC/EQUAD + ECORR, notebook seeds).
 cw_catalog.npz   add_catalog_of_cws through both numba kernels of the reference (40 and 1200 sources).
+transients.npz   add_burst / add_noise_transient / add_gw_memory with Gaussian-sine waveforms.
+population.npz   add_gwb_plus_outlier_cws on a 1500-binary synthetic population (userSpec GWB + 22 outlier CWs).
 """
 import glob
 import json
@@ -373,6 +375,76 @@ def gen_cw_catalog(ref):
     print("cw_catalog:", len(out), "arrays")
 
 
+def population_inputs(seed=31):
+    """a small binned SMBHB population in holodeck's layout: vals = [Mtot (g), q, z, f_obs (Hz)], weights, bin edges"""
+    rng = np.random.default_rng(seed)
+    n = 1500
+    T_obs = 10 * 365.25 * 86400.0
+    fobs = np.arange(1, 8) / T_obs                       # 6 bins
+    msol = 1.988409870698051e33
+    mtot = 10 ** rng.uniform(8.5, 10.3, n) * msol
+    mrat = rng.uniform(0.1, 1.0, n)
+    redz = rng.uniform(0.02, 2.0, n)
+    fo = 10 ** rng.uniform(np.log10(fobs[0] * 0.8), np.log10(fobs[-1] * 1.1), n)   # a few fall outside the edges
+    last = np.nonzero((fo >= fobs[-2]) & (fo < fobs[-1]))[0]
+    fo[last[2:]] = fobs[1] * 1.3                         # leave only two binaries in the last bin (< outlier_per_bin)
+    weights = 10 ** rng.uniform(-1.0, 3.0, n)
+    weights[5] = weights[17] = 50.0                      # an exact tie is broken by position
+    mtot[17], mrat[17], redz[17], fo[17] = mtot[5], mrat[5], redz[5], fo[5]
+    return np.array([mtot, mrat, redz, fo]), weights, fobs, T_obs
+
+
+def gen_population(ref):
+    """add_gwb_plus_outlier_cws (deterministic.py:565-715) on 3 x 200 TOAs: loudest 4 binaries per bin as CWs, the rest as a
+    user-spectrum GWB; holodeck is the formula stub in oracle/_stubs/holodeck (parity with holodeck itself unpinned)."""
+    psrs, mjd0 = synth_array(ref, 3, 200, seed=123, burst=1, backends=("X",))
+    out = pulsar_inputs("", psrs, mjd0)
+    vals, weights, fobs, T_obs = population_inputs()
+    out.update(vals=vals, weights=weights, fobs=fobs, T_obs=np.array(T_obs))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ret = ref.deterministic.add_gwb_plus_outlier_cws(psrs, vals, weights, fobs, T_obs, outlier_per_bin=4, seed=4711)
+    names = ("f_centers", "free_spec", "outlier_fo", "outlier_hs", "outlier_mc", "outlier_dl", "gwthetas", "gwphis", "phases",
+             "psis", "incs")
+    for k, v in zip(names, ret):
+        out["ret_" + k] = np.asarray(v)
+    out["gwb_days"] = np.array([sig(p, "gwb") for p in psrs])
+    out["cw_catalog"] = np.array([sig(p, "cw_catalog") for p in psrs])
+    out["shift_days"] = np.array([np.sum(np.array(p.toas.shifts_day, dtype=np.longdouble), axis=0).astype(np.float64) for p in psrs])
+    np.savez_compressed(os.path.join(OUT, "population.npz"), **out)
+    print("population:", len(ret[2]), "outliers; free_spec", ret[1])
+
+
+BURST = dict(t0=2.2e8, tau=4.0e7, f=3.0e-8, a_plus=2.0e-7, a_cross=1.3e-7)
+
+
+def burst_plus(t, b=BURST):
+    return b["a_plus"] * np.exp(-0.5 * ((t - b["t0"]) / b["tau"]) ** 2) * np.cos(2 * np.pi * b["f"] * (t - b["t0"]))
+
+
+def burst_cross(t, b=BURST):
+    return b["a_cross"] * np.exp(-0.5 * ((t - b["t0"]) / b["tau"]) ** 2) * np.sin(2 * np.pi * b["f"] * (t - b["t0"]))
+
+
+def gen_transients(ref):
+    """add_burst (with and without the quadratic fit), add_noise_transient, add_gw_memory (deterministic.py:718-884)."""
+    psrs, mjd0 = synth_array(ref, 3, 150, seed=321, burst=1, backends=("X",))
+    out = pulsar_inputs("", psrs, mjd0)
+    tref = 53000 * 86400
+    for case, rq in (("burst", False), ("burst_quad", True)):
+        ps, _ = synth_array(ref, 3, 150, seed=321, burst=1, backends=("X",))
+        for p in ps:
+            ref.deterministic.add_burst(p, 1.1, 4.0, burst_plus, burst_cross, psi=0.4, tref=tref, remove_quad=rq)
+        out[case] = np.array([sig(p, "burst") for p in ps])
+    ps, _ = synth_array(ref, 3, 150, seed=321, burst=1, backends=("X",))
+    for p in ps:
+        ref.deterministic.add_noise_transient(p, burst_plus, tref=tref)
+        ref.deterministic.add_gw_memory(p, 3e-14, 0.7, 5.1, 0.9, 55500.0)
+    out["noise_transient"] = np.array([sig(p, "noise_transient") for p in ps])
+    out["gw_memory"] = np.array([sig(p, "gw_memory") for p in ps])
+    np.savez_compressed(os.path.join(OUT, "transients.npz"), **out)
+    print("transients:", {k: float(np.sqrt(np.mean(out[k] ** 2))) for k in ("burst", "burst_quad", "noise_transient", "gw_memory")})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = rr.load_reference()
@@ -382,5 +454,7 @@ if __name__ == "__main__":
     gen_variants(ref)
     gen_c3_mini(ref)
     gen_cw_catalog(ref)
+    gen_population(ref)
+    gen_transients(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -3,8 +3,10 @@
 Mirrors ``pta_replicator/deterministic.py:13-185`` (single source) and ``:188-561`` (catalogue + its two numba
 kernels).  For a single source the scalar prefactors (antenna patterns, chirp factors) are computed on the host with
 the reference's own expressions and the per-TOA waveform (four pow, two sincos) runs in the ``pta_cgw`` kernel; for a
-catalogue everything, prefactors included, runs on the device (``pta_cw_catalog``).  The population / burst / memory
-injectors of the reference remain outside this round's scope.
+catalogue everything, prefactors included, runs on the device (``pta_cw_catalog``).  ``add_gwb_plus_outlier_cws``
+(``:565-715``) is host bookkeeping around ``add_gwb`` and the catalogue kernel.  ``add_burst`` / ``add_noise_transient`` /
+``add_gw_memory`` (``:718-884``) evaluate USER-SUPPLIED Python callables (or a one-line ramp) per TOA: host work by
+construction - there is no device path for them to fall back from - kept so that a reference script finds every name.
 """
 import ctypes
 
@@ -122,3 +124,126 @@ def add_catalog_of_cws(psr, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_li
                               "tref": tref}, dt)
     psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
     psr.update_residuals()
+
+
+def split_population(vals, weights, fobs, T_obs, outlier_per_bin=100, population=None):
+    """Host bookkeeping of deterministic.py:617-676: characteristic strain of every binary, the ``outlier_per_bin`` loudest
+    of each frequency bin set aside (padded slots stay zero), the remainder summed into the free spectrum.
+    Returns (f_centers, free_spec, outlier_hs, outlier_fo, outlier_mc [Msun, observer frame], outlier_dl [Mpc])."""
+    from . import _population as pop
+    population = population or pop.Population
+    vals = np.asarray(vals, dtype=np.float64)
+    weights = np.asarray(weights, dtype=np.float64)
+    fobs = np.asarray(fobs, dtype=np.float64)
+
+    f_centers = np.array([(fobs[i + 1] + fobs[i]) / 2 for i in range(fobs.size - 1)])
+    mc = population.chirp_mass(*population.component_masses(vals[0], vals[1]))   # rest frame
+    rz = vals[2, :]
+    frst = vals[3] * (1.0 + rz)
+    dc = population.comoving_distance_cm(rz)
+    dl = np.copy(dc) * (1.0 + rz)
+    hs = population.gw_strain_source(mc, dc, frst / 2)
+    fo = vals[-1]
+    mc = mc * (1.0 + rz)                                                          # observer frame for the injections
+
+    nbin = fobs.shape[0] - 1
+    freq_idxs = np.digitize(fo, fobs)
+    free_spec = np.ones(nbin) * 1e-100
+    outlier_hs, outlier_fo, outlier_mc, outlier_dl = (np.zeros(nbin * outlier_per_bin) for _ in range(4))
+    weighted_h_square = weights * hs ** 2 * fo * T_obs
+    for k in range(nbin):
+        members = np.nonzero((freq_idxs - 1) == k)[0]
+        order = members[np.argsort(weighted_h_square[members])[::-1]]            # loudest first, ties as the reference
+        top = order[:outlier_per_bin]
+        sl = slice(outlier_per_bin * k, outlier_per_bin * k + len(top))
+        outlier_hs[sl] = weighted_h_square[top]
+        outlier_fo[sl] = fo[top]
+        outlier_mc[sl] = mc[top] / pop.MSOL_CGS
+        outlier_dl[sl] = dl[top] / pop.PC_CGS / 1e6
+        free_spec[k] += np.sum(weighted_h_square[order[outlier_per_bin:]])
+    return f_centers, free_spec, outlier_hs, outlier_fo, outlier_mc, outlier_dl
+
+
+def add_gwb_plus_outlier_cws(psrs, vals, weights, fobs, T_obs, outlier_per_bin=100, seed=None, population=None):
+    """Realistic data set from a binned SMBHB population: the ``outlier_per_bin`` loudest binaries of every frequency bin
+    are injected one by one (add_catalog_of_cws, one device pass per pulsar), the rest as a GWB with their summed spectrum
+    (add_gwb(userSpec=...)).  Arguments and the eleven return values as deterministic.py:565-715; ``population`` swaps the
+    holodeck-equivalent helpers (see _population.py)."""
+    from .red_noise import add_gwb
+    f_centers, free_spec, outlier_hs, outlier_fo, outlier_mc, outlier_dl = split_population(vals, weights, fobs, T_obs,
+                                                                                            outlier_per_bin, population)
+    FreeSpec = np.array([f_centers, np.sqrt(free_spec)]).T
+    add_gwb(psrs, None, None, userSpec=FreeSpec, howml=10, seed=seed)
+
+    outlier_hs = outlier_hs[np.where(outlier_hs > 0)]
+    outlier_fo = outlier_fo[np.where(outlier_fo > 0)]
+    outlier_mc = outlier_mc[np.where(outlier_mc > 0)]
+    outlier_dl = outlier_dl[np.where(outlier_dl > 0)]
+    N_CW = outlier_hs.shape[0]
+    # the global legacy stream continues where add_gwb left it (:696-700)
+    random_gwthetas = np.arccos(np.random.uniform(low=-1.0, high=1.0, size=N_CW))
+    random_gwphis = np.random.uniform(low=0.0, high=2 * np.pi, size=N_CW)
+    random_phases = np.random.uniform(low=0.0, high=2 * np.pi, size=N_CW)
+    random_psis = np.random.uniform(low=0.0, high=np.pi, size=N_CW)
+    random_incs = np.arccos(np.random.uniform(low=-1.0, high=1.0, size=N_CW))
+
+    for pulsar in psrs:
+        add_catalog_of_cws(pulsar, gwtheta_list=random_gwthetas, gwphi_list=random_gwphis, mc_list=outlier_mc,
+                           dist_list=outlier_dl, fgw_list=outlier_fo, phase0_list=random_phases, psi_list=random_psis,
+                           inc_list=random_incs, pdist=1.0, pphase=None, psrTerm=True, evolve=True, phase_approx=False,
+                           tref=53000 * 86400)
+    return (f_centers, free_spec, outlier_fo, outlier_hs, outlier_mc, outlier_dl, random_gwthetas, random_gwphis,
+            random_phases, random_psis, random_incs)
+
+
+def antenna_patterns(psr, gwtheta, gwphi):
+    """(F+, Fx, cosMu) of a pulsar for a source at (gwtheta, gwphi) - Sesana et al. 2010 / Ellis et al. 2012 convention
+    (deterministic.py:64-95, :732-761)."""
+    ct, st, cp, sp = np.cos(gwtheta), np.sin(gwtheta), np.cos(gwphi), np.sin(gwphi)
+    m = np.array([sp, -cp, 0.0])
+    n = np.array([-ct * cp, -ct * sp, st])
+    omhat = np.array([-st * cp, -st * sp, -ct])
+    ra, dec = ra_dec(psr)
+    ptheta, pphi = np.pi / 2 - dec, ra
+    phat = np.array([np.sin(ptheta) * np.cos(pphi), np.sin(ptheta) * np.sin(pphi), np.cos(ptheta)])
+    fplus = 0.5 * (np.dot(m, phat) ** 2 - np.dot(n, phat) ** 2) / (1 + np.dot(omhat, phat))
+    fcross = (np.dot(m, phat) * np.dot(n, phat)) / (1 + np.dot(omhat, phat))
+    return fplus, fcross, -np.dot(omhat, phat)
+
+
+def _record(psr, signal_name, params, res):
+    dt = np.asarray(res, dtype=np.float64) * u.s
+    psr.update_added_signals("{}_".format(psr.name) + signal_name, params, dt)
+    psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
+    psr.update_residuals()
+
+
+def add_burst(psr, gwtheta, gwphi, waveform_plus, waveform_cross, psi=0.0, tref=0, remove_quad=False, signal_name="burst"):
+    """GW burst of arbitrary (callable) plus/cross waveforms, elliptical polarisation; arguments as deterministic.py:718-731.
+    The callables receive ``t - tref`` in seconds.  Host only (see module docstring)."""
+    fplus, fcross, _ = antenna_patterns(psr, gwtheta, gwphi)
+    toas = psr.toas.get_mjds().value * 86400 - tref
+    hplus, hcross = waveform_plus(toas), waveform_cross(toas)
+    c2, s2 = np.cos(2 * psi), np.sin(2 * psi)
+    res = -fplus * (hplus * c2 - hcross * s2) - fcross * (hplus * s2 + hcross * c2)
+    if remove_quad:  # mimic the spin / spin-down fit (:778-780)
+        pp = np.polyfit(np.array(toas, dtype=np.double), np.array(res, dtype=np.double), 2)
+        res = res - pp[0] * toas ** 2 - pp[1] * toas - pp[2]
+    _record(psr, signal_name, {"gwtheta": gwtheta, "gwphi": gwphi, "waveform_plus": waveform_plus, "waveform_cross": waveform_cross,
+                               "psi": psi, "tref": tref, "remove_quad": remove_quad}, res)
+
+
+def add_noise_transient(psr, waveform, tref=0, signal_name="noise_transient"):
+    """Incoherent transient of arbitrary (callable) waveform in one pulsar (deterministic.py:796-819).  Host only."""
+    toas = psr.toas.get_mjds().value * 86400 - tref
+    _record(psr, signal_name, {"waveform": waveform, "tref": tref}, waveform(toas))
+
+
+def add_gw_memory(psr, strain, gwtheta, gwphi, bwm_pol, t0_mjd, signal_name="gw_memory"):
+    """Burst with memory: a ramp ``pol * strain * (t - t0)`` after the burst epoch (deterministic.py:822-884).  Host only."""
+    fplus, fcross, _ = antenna_patterns(psr, gwtheta, gwphi)
+    pol = np.cos(2 * bwm_pol) * fplus + np.sin(2 * bwm_pol) * fcross
+    toas = psr.toas.get_mjds().value * 86400
+    t0_sec = t0_mjd * 86400
+    res = np.where(toas < t0_sec, 0.0, pol * strain * (toas - t0_sec))
+    _record(psr, signal_name, {"strain": strain, "gwtheta": gwtheta, "gwphi": gwphi, "bwm_pol": bwm_pol, "t0_mjd": t0_mjd}, res)

@@ -57,6 +57,7 @@ class ReplicaEngine:
         self._ec = None
         self._gw = None
         self._det = None
+        self._delays = None
         self._prepared = False
         # frequency -> time transform of the GWB in throughput mode: "auto" = chirp-z FFT when it fits, else the MFMA DFT-GEMM
         self.gwb_transform = "auto"
@@ -90,6 +91,16 @@ class ReplicaEngine:
     def add_cgw(self, **kw):
         """a continuous-wave source shared by all pulsars (deterministic.py:13-185); same keyword arguments."""
         self._det = (self._det or []) + [kw]
+        self._prepared = False
+
+    def add_delays(self, delays):
+        """any precomputed deterministic delay (seconds; one array per pulsar or one concatenated array), e.g. the
+        ``added_signals_time`` entry left by add_burst / add_gw_memory / add_catalog_of_cws: added to every realisation."""
+        d = np.concatenate([np.asarray(x, dtype=np.float64).ravel() for x in delays]) if isinstance(delays, (list, tuple)) \
+            else np.asarray(delays, dtype=np.float64).ravel()
+        if d.shape != (self.n_toa,):
+            raise ValueError("delays must cover all {} TOAs, got {}".format(self.n_toa, d.shape))
+        self._delays = d if getattr(self, "_delays", None) is None else self._delays + d
         self._prepared = False
 
     # ---------------------------------------------------------------- helpers -------------------
@@ -259,9 +270,10 @@ class ReplicaEngine:
 
         # ---- deterministic signals (CGW), summed once
         pl.det = None
-        if self._det:
-            self.d_det = dv.zeros((N,))
-            for kw in self._det:
+        extra = getattr(self, "_delays", None)
+        if self._det or extra is not None:
+            self.d_det = dv.zeros((N,)) if extra is None else dv.f64(extra)
+            for kw in self._det or []:
                 for a in range(P):
                     ra, dec = ra_dec(self.psrs[a])
                     par, _, _, _ = det.cgw_parameters(np.pi / 2 - dec, ra, **{k: v for k, v in kw.items() if k != "signal_name"})

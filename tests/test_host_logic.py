@@ -162,3 +162,80 @@ def test_ecliptic_branch_restatement_is_sane():
     assert abs(np.degrees(ra) / 15 - (19 + 9 / 60 + 47.4 / 3600)) < 1e-3 and abs(np.degrees(dec) + (37 + 44 / 60 + 14.5 / 3600)) < 2e-3
     ra, dec = ecliptic_to_equatorial(286.863485782621126, 32.321482985635249, "B1855+09")  # B name -> epoch 1950
     assert abs(np.degrees(ra) / 15 - (18 + 55 / 60 + 13.7 / 3600)) < 2e-3 and abs(np.degrees(dec) - (9 + 39 / 60 + 13 / 3600)) < 5e-3
+
+
+def test_population_split_matches_the_reference_bookkeeping():
+    """deterministic.py:617-676 on the host: strain of every binary, loudest-per-bin selection (incl. an exact tie and a bin
+    with fewer members than outlier_per_bin), free spectrum of the rest - against the reference run on the holodeck stub."""
+    from pta_replicator_amd.deterministic import split_population
+    z = load("population.npz")
+    fc, free, hs, fo, mc, dl = split_population(z["vals"], z["weights"], z["fobs"], float(z["T_obs"]), outlier_per_bin=4)
+    assert np.array_equal(fc, z["ret_f_centers"])
+    assert np.max(np.abs(free / z["ret_free_spec"] - 1)) < 1e-13 and free[-1] == 1e-100
+    assert hs.shape == (24,) and np.count_nonzero(hs) == 22
+    assert np.array_equal(fo[fo > 0], z["ret_outlier_fo"])
+    for got, key in ((hs, "outlier_hs"), (mc, "outlier_mc"), (dl, "outlier_dl")):
+        assert np.max(np.abs(got[got > 0] / z["ret_" + key] - 1)) < 1e-13, key
+
+
+def test_population_helpers_against_closed_forms():
+    from pta_replicator_amd import _population as pop
+    z = np.array([0.0, 1e-3, 0.5, 3.0, 12.0])
+    try:
+        om = pop.OMEGA_M
+        pop.OMEGA_M = 1.0          # Einstein-de Sitter: d_c = 2c/H0 (1 - 1/sqrt(1+z))
+        eds = 2 * pop.C_CGS * 1e-5 / pop.H0_KM_S_MPC * (1 - 1 / np.sqrt(1 + z)) * pop.PC_CGS * 1e6
+        assert np.allclose(pop.comoving_distance_cm(z), eds, rtol=1e-12, atol=0)
+    finally:
+        pop.OMEGA_M = om
+    assert abs(pop.comoving_distance_cm(1.0)[0] / (pop.PC_CGS * 1e6) - 3363.39) < 0.01     # WMAP9, no radiation
+    m1, m2 = pop.component_masses(3.0, 0.5)
+    assert (m1, m2) == (2.0, 1.0) and abs(pop.chirp_mass(m1, m2) - 2 ** 0.6 / 3 ** 0.2) < 1e-15
+    # h_s of a 1e9 Msun chirp mass at 100 Mpc, f_gw = 2 f_orb = 1e-8 Hz: 8/sqrt(10) (G Mc)^(5/3) (pi f_gw)^(2/3) / (c^4 d)
+    mcg, d, fgw = 1e9 * pop.MSOL_CGS, 100e6 * pop.PC_CGS, 1e-8
+    expect = 8 / np.sqrt(10) * (pop.G_CGS * mcg) ** (5 / 3) * (np.pi * fgw) ** (2 / 3) / (pop.C_CGS ** 4 * d)
+    assert abs(pop.gw_strain_source(mcg, d, fgw / 2) / expect - 1) < 1e-13
+
+
+_BURST = dict(t0=2.2e8, tau=4.0e7, f=3.0e-8, a_plus=2.0e-7, a_cross=1.3e-7)      # as oracle/gen_golden.py
+
+
+def _burst_plus(t, b=_BURST):
+    return b["a_plus"] * np.exp(-0.5 * ((t - b["t0"]) / b["tau"]) ** 2) * np.cos(2 * np.pi * b["f"] * (t - b["t0"]))
+
+
+def _burst_cross(t, b=_BURST):
+    return b["a_cross"] * np.exp(-0.5 * ((t - b["t0"]) / b["tau"]) ** 2) * np.sin(2 * np.pi * b["f"] * (t - b["t0"]))
+
+
+def test_burst_transient_and_memory_injectors_match_the_reference():
+    """deterministic.py:718-884 - host-only by construction (user callables); golden from the unmodified reference."""
+    from pta_replicator_amd.deterministic import add_burst, add_gw_memory, add_noise_transient
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    from helpers import relrms
+    z = load("transients.npz")
+    tref = 53000 * 86400
+
+    def fresh():
+        out = []
+        for i in range(3):
+            p = SimulatedPulsar(toas=ArrayTOAs(mjd_ld(z, "", i), z[f"err_us_{i}"]), name=str(z["names"][i]),
+                                loc={"RAJ": float(z["raj_hours"][i]), "DECJ": float(z["decj_deg"][i])})
+            make_ideal(p)
+            out.append(p)
+        return out
+
+    def sig(p, key):
+        return np.asarray(p.added_signals_time[f"{p.name}_{key}"].value, dtype=np.float64)
+
+    for case, rq in (("burst", False), ("burst_quad", True)):
+        for a, p in enumerate(fresh()):
+            add_burst(p, 1.1, 4.0, _burst_plus, _burst_cross, psi=0.4, tref=tref, remove_quad=rq)
+            assert relrms(sig(p, "burst"), z[case][a]) < 1e-12, (case, a)
+    for a, p in enumerate(fresh()):
+        add_noise_transient(p, _burst_plus, tref=tref)
+        add_gw_memory(p, 3e-14, 0.7, 5.1, 0.9, 55500.0)
+        assert relrms(sig(p, "noise_transient"), z["noise_transient"][a]) < 1e-12
+        assert relrms(sig(p, "gw_memory"), z["gw_memory"][a]) < 1e-12
+        with pytest.raises(ValueError):
+            add_gw_memory(p, 3e-14, 0.7, 5.1, 0.9, 55500.0)          # same signal twice (simulate.py:85-86)
