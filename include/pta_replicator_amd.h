@@ -173,6 +173,11 @@ int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, i
  * scipy.interpolate.interp1d(kind="linear") delegates to; red_noise.py:286-287).           */
 int pta_gwb_bracket(const double *ut, int npts, const double *toa_s, int N, int32_t *jlo, void *stream);
 
+/* w[i] = (toa_s[i] - ut[j]) / (ut[j+1] - ut[j]), j = jlo[i]: the realisation-independent half of the linear
+ * interpolation red_noise.py:286-287, so the fused kernel evaluates fp[j] + (fp[j+1] - fp[j]) * w per realisation
+ * (no division, no grid lookups in the hot loop; differs from interp1d's slope form by rounding only).   */
+int pta_gwb_weights(const double *ut, int npts, const double *toa_s, const int32_t *jlo, int N, double *w, void *stream);
+
 /* out[r*ld_out + i] (+)= slope*(toa_s[i] - ut[j]) + G[j],  j = jlo[i], G row = (r, psr_of_toa[i]).
  * scale multiplies the result (1/86400 gives the day-valued delay of red_noise.py:292).     */
 int pta_gwb_interp(const double *G, int64_t ldg, int P, int npts, const double *ut, const double *toa_s,
@@ -223,9 +228,8 @@ typedef struct {
   int64_t ldf;
   const double *rn_coef;      /* [R x n_psr x rn_k] sqrt(prior)*z, from pta_engine_rn_coef */
   const double *gw_G;         /* [R x n_psr x gw_npts] mixed GWB grid series */
-  const double *gw_ut;        /* [gw_npts] */
-  const double *toa_s;        /* [n_toa] */
-  const int32_t *gw_jlo;      /* [n_toa] */
+  const int32_t *gw_jlo;      /* [n_toa] bracket of the TOA on the coarse grid, from pta_gwb_bracket */
+  const double *gw_w;         /* [n_toa] (t - ut[j]) / (ut[j+1] - ut[j]), from pta_gwb_weights */
   const double *wn_a;         /* [n_toa] efac*sigma */
   const double *wn_b;         /* [n_toa] efac*equad (t2equad) or equad (tnequad) */
   const int32_t *epoch_of;    /* [n_toa] epoch index inside the pulsar */

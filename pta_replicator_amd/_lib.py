@@ -36,7 +36,7 @@ class EnginePlan(ctypes.Structure):
         ("n_tiles", c_int32),
         ("tile_psr", _P), ("tile_start", _P), ("tile_count", _P), ("tile_ep0", _P), ("tile_epn", _P),
         ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
-        ("gw_ut", _P), ("toa_s", _P), ("gw_jlo", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
+        ("gw_jlo", _P), ("gw_w", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
         ("ecorr_toa", _P), ("det", _P),
     ]
 
@@ -70,6 +70,7 @@ _SIGNATURES = {
     "pta_gwb_czt": (c_int, [c_uint64, c_uint64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "pta_gwb_mix": (c_int, [_P, c_int, _P, c_int, c_int, c_int64, _P, _P]),
     "pta_gwb_bracket": (c_int, [_P, c_int, _P, c_int, _P, _P]),
+    "pta_gwb_weights": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "pta_gwb_interp": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_double, _P, c_int64, c_int, _P]),
     "pta_cgw": (c_int, [_P, c_int, _P, _P, c_int, _P]),
     "pta_cw_catalog_workspace": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),

@@ -93,16 +93,14 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
   }
   if (pl.gw_npts > 0) {  // GWB: interpolate the mixed grid series (red_noise.py:286-287)
     const int j = pl.gw_jlo[i];
-    const double x = pl.toa_s[i];
-    const double x0 = pl.gw_ut[j], dx = pl.gw_ut[j + 1] - x0;
+    const double wgt = pl.gw_w[i];
     const double *__restrict__ gbase = pl.gw_G + ((int64_t)rb * P + a) * pl.gw_npts;
     const int64_t rstride = (int64_t)P * pl.gw_npts;
 #pragma unroll
     for (int q = 0; q < ENG_RB; ++q) {
       int qq = (rb + q < R) ? q : 0;
       const double *g = gbase + qq * rstride;
-      double slope = (g[j + 1] - g[j]) / dx;
-      v[q] = v[q] + (slope * (x - x0) + g[j]);
+      v[q] = v[q] + ((g[j + 1] - g[j]) * wgt + g[j]);
     }
   }
   if (pl.wn_a) {  // EFAC/EQUAD: (efac sigma) z1 + (efac equad | equad) z2 (white_noise.py:105-109)
@@ -206,14 +204,13 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
     for (int g = 0; g < 4; ++g) v[g] = acc[j][g];
     if (pl.gw_npts > 0) {  // GWB: interpolate the mixed grid series (red_noise.py:286-287)
       const int jl = pl.gw_jlo[i];
-      const double x = pl.toa_s[i];
-      const double x0 = pl.gw_ut[jl], dx = pl.gw_ut[jl + 1] - x0;
+      const double wgt = pl.gw_w[i];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int r = min(rb + quad + 4 * g, R - 1);
         const double *gp = pl.gw_G + ((int64_t)r * P + a) * pl.gw_npts;
-        double slope = (gp[jl + 1] - gp[jl]) / dx;
-        v[g] = v[g] + (slope * (x - x0) + gp[jl]);
+        const double y0 = gp[jl];
+        v[g] = v[g] + ((gp[jl + 1] - y0) * wgt + y0);
       }
     }
     if (pl.wn_a) {  // EFAC/EQUAD (white_noise.py:105-109)
@@ -262,7 +259,7 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_REQUIRE(p.n_tiles > 0 && p.tile_psr && p.tile_start && p.tile_count && p.tile_ep0 && p.tile_epn && p.idx_in_psr, PTA_E_ARG,
               "pta_engine_synth: tile table / idx_in_psr missing");
   PTA_REQUIRE(p.rn_k == 0 || (p.Ft && p.rn_coef && p.ldf >= p.n_toa), PTA_E_ARG, "pta_engine_synth: red-noise inputs missing");
-  PTA_REQUIRE(p.gw_npts == 0 || (p.gw_G && p.gw_ut && p.gw_jlo && p.toa_s && p.gw_npts >= 2), PTA_E_ARG,
+  PTA_REQUIRE(p.gw_npts == 0 || (p.gw_G && p.gw_jlo && p.gw_w && p.gw_npts >= 2), PTA_E_ARG,
               "pta_engine_synth: GWB inputs missing");
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");

@@ -306,6 +306,22 @@ extern "C" int pta_gwb_bracket(const double *ut, int npts, const double *toa_s, 
   return PTA_OK;
 }
 
+__global__ void k_gwb_weights(const double *__restrict__ ut, int npts, const double *__restrict__ toa_s,
+                              const int32_t *__restrict__ jlo, int N, double *__restrict__ w) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int j = max(0, min(jlo[i], npts - 2));
+  w[i] = (toa_s[i] - ut[j]) / (ut[j + 1] - ut[j]);
+}
+
+extern "C" int pta_gwb_weights(const double *ut, int npts, const double *toa_s, const int32_t *jlo, int N, double *w, void *stream) {
+  PTA_REQUIRE(ut && toa_s && jlo && w, PTA_E_ARG, "pta_gwb_weights: NULL argument");
+  PTA_REQUIRE(npts >= 2 && N > 0, PTA_E_ARG, "pta_gwb_weights: npts=%d N=%d", npts, N);
+  hipLaunchKernelGGL(k_gwb_weights, dim3(pta_cdiv(N, 256)), dim3(256), 0, pta_stream(stream), ut, npts, toa_s, jlo, N, w);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
 __device__ __forceinline__ double pta_lerp(const double *__restrict__ g, const double *__restrict__ ut, int j, double x) {
   double slope = (g[j + 1] - g[j]) / (ut[j + 1] - ut[j]);  // numpy.interp: slope*(x - xp[j]) + fp[j]
   return slope * (x - ut[j]) + g[j];

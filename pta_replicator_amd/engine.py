@@ -119,7 +119,6 @@ class ReplicaEngine:
         pl = self.plan
         pl.n_toa, pl.n_psr = N, P
         pl.idx_in_psr = self.d_idx_in.data_ptr()
-        pl.toa_s = self.d_toa_s.data_ptr()
 
         # ---- red noise: Ft [K, N] over the concatenated TOAs and amp = sqrt(prior) [P, K]
         pl.rn_k = 0
@@ -266,7 +265,10 @@ class ReplicaEngine:
             self.d_jlo = dv.empty((N,), dtype=torch.int32)
             _lib.call("pta_gwb_bracket", dv.ptr(self.d_ut), npts, dv.ptr(self.d_toa_s), N, dv.ptr(self.d_jlo), s)
             torch.cuda.current_stream().synchronize()
-            pl.gw_npts, pl.gw_ut, pl.gw_jlo = npts, self.d_ut.data_ptr(), self.d_jlo.data_ptr()
+            self.d_gw_w = dv.empty((N,))
+            _lib.call("pta_gwb_weights", dv.ptr(self.d_ut), npts, dv.ptr(self.d_toa_s), dv.ptr(self.d_jlo), N, dv.ptr(self.d_gw_w), s)
+            torch.cuda.current_stream().synchronize()
+            pl.gw_npts, pl.gw_jlo, pl.gw_w = npts, self.d_jlo.data_ptr(), self.d_gw_w.data_ptr()
 
         # ---- deterministic signals (CGW), summed once
         pl.det = None
