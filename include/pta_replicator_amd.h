@@ -157,9 +157,10 @@ int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const dou
  * ~0.5 MFLOP per row instead of 3.6 MFLOP of dense DFT.  pta_gwb_czt_setup fills pre[2*4096] (pre-chirp with
  * sqrtC), FB[2*4096] (chirp spectrum / 4096, digit-reversed order), tw[2*4096] (FFT twiddles), post[2*npts].
  * pta_gwb_czt: w == NULL draws on chip (stream (GWB, a), pair k, like pta_gwb_idft_rng), else w[R*P x ldw]
- * interleaved (re, im) rows as in pta_gwb_idft.                                              */
+ * interleaved (re, im) rows as in pta_gwb_idft (ldw = 0: one row of draws shared by all rows - timing probe).  */
 int pta_gwb_czt_fits(int Nf, int npts, int i0);
-int pta_set_czt_variant(int variant); /* 0 (default): one workgroup barrier per FFT pass; 1: fused wave-local pass pairs */
+int pta_set_czt_variant(int variant); /* 0 (default): six LDS exchanges, draws / product / output in registers, computed twiddles;
+                                          1: every stage through LDS with table twiddles (cross-check); 10+f: ladder step f */
 int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *pre, double *FB, double *tw,
                       double *post, void *stream);
 int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,

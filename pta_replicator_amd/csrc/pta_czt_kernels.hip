@@ -85,71 +85,89 @@ extern "C" int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, 
 
 extern "C" int pta_gwb_czt_fits(int Nf, int npts, int i0) { return czt_fits(Nf, npts, i0) ? 1 : 0; }
 
-// order LDS traffic of one wave without a workgroup barrier (the hardware executes a wave's LDS instructions in order;
-// this only stops the compiler from moving accesses across the hand-over point)
-__device__ __forceinline__ void pta_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// QA = number of 512-strided input elements per first-pass butterfly that can be non-zero (ceil(Kf / 512)): 6 at the
-// headline Nf; known at compile time so that the draw chains are straight-line code with all loads hoisted
-template <bool RNG, int QA>
+// One workgroup per (realisation, pulsar) row.  FUSE selects how much stays in registers between LDS exchanges:
+//   bit 0: forward s=1 butterfly, chirp-spectrum product and inverse s=1 butterfly in one go (two exchanges fewer);
+//   bit 1: the last butterfly writes the npts-sample window straight to memory;
+//   bit 2: the first butterfly starts from registers (draws generated per thread for its own 512-strided elements);
+//   bit 3: one twiddle load per butterfly, the rest by squaring / products (pta_fft_twiddles<.., 1>).
+// FUSE = 15 is the production kernel: 6 LDS exchanges instead of 10, and - what mattered most on MI355X - 6 instead of 56
+// global twiddle loads per thread (the q-strided twiddle gathers, not LDS or the barriers, bounded the first version:
+// 3.2 -> 2.0 ms per 65 280 rows; rocprofv3 SQ_INSTS_VALU now accounts for ~95 % of the time).  FUSE = 0 (every stage through
+// LDS, table twiddles) is kept as the cross-check.
+template <bool RNG, bool FAST, int FUSE>
 __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
-                                                                int M, int P, int Nf, int npts, int i0,
-                                                                const double *__restrict__ pre, const double *__restrict__ FB,
-                                                                const double *__restrict__ tw, const double *__restrict__ post,
-                                                                double *__restrict__ G0, int64_t ldg, int fast) {
+                                                                  int M, int P, int Nf, int npts, int i0,
+                                                                  const double *__restrict__ pre, const double *__restrict__ FB,
+                                                                  const double *__restrict__ tw, const double *__restrict__ post,
+                                                                  double *__restrict__ G0, int64_t ldg) {
   __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
   const int Kf = Nf - 2;
   const uint64_t real = r0 + (uint64_t)(row / P);
   const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(row % P));
-  pta_cplx v[8], tv[8];
-  int b, o;
-
-  // ---- forward, column pair.  The s = 512 butterfly starts from registers: element o + 512 q is the chirped,
-  // spectrum-weighted draw A[t] = w[a, t+1] * pre[t] (pair k = t+1 <-> Re, Im of w[a,k], red_noise.py:240), zero for t >= Kf
-  pta_fft_map<9>(tid, b, o);
-  pta_fft_twiddles<9>(tw, o, tv);
-  {
-    const pta_cplx *pre2 = reinterpret_cast<const pta_cplx *>(pre);
-    pta_cplx pc[QA];
-#pragma unroll
-    for (int q = 0; q < QA; ++q) pc[q] = pre2[min(o + 512 * q, Kf - 1)];
+  const pta_cplx *pre2 = reinterpret_cast<const pta_cplx *>(pre);
+  constexpr int TW = (FUSE & 8) ? 1 : 3;
+  // the inverse passes use the same twiddles as the forward ones; through an opaque copy of the pointer the compiler reloads
+  // them (L1/L2 hits) instead of carrying 28 registers per pass across the whole kernel in scratch
+  const double *twi = tw;
+  asm volatile("" : "+s"(twi));
+  if (FUSE & 4) {
+    int b, o;
+    pta_cplx v[8], tv[8];
+    pta_fft_map<9>(tid, b, o);
+    pta_fft_twiddles<9, TW>(tw, o, tv);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      if (q < QA) {
-        const int t = min(o + 512 * q, Kf - 1);
+      const int t = o + 512 * q;
+      v[q] = {0.0, 0.0};
+      if (t < Kf) {  // uniform per q except in the one 512-block that straddles Kf
         double wr, wi;
         if (RNG) {
-          pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, fast);
+          pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, FAST ? 1 : 0);
         } else {
           wr = w[(int64_t)row * ldw + 2 * (t + 1)];
           wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
         }
-        const bool on = (o + 512 * q) < Kf;
-        v[q] = {on ? wr * pc[q].re - wi * pc[q].im : 0.0, on ? wr * pc[q].im + wi * pc[q].re : 0.0};
-      } else {
-        v[q] = {0.0, 0.0};
+        const pta_cplx pc = pre2[t];
+        v[q] = {wr * pc.re - wi * pc.im, wr * pc.im + wi * pc.re};
       }
     }
+    pta_fft_core<false, 9>(v, tv);
+    pta_fft_store<9>(re, im, b, o, v);
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {
+      const int t = tid + PTA_FFT_THREADS * i;
+      double ar = 0.0, ai = 0.0;
+      if (t < Kf) {
+        double wr, wi;
+        if (RNG) {
+          pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, FAST ? 1 : 0);
+        } else {
+          wr = w[(int64_t)row * ldw + 2 * (t + 1)];
+          wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
+        }
+        const pta_cplx pc = pre2[t];
+        ar = wr * pc.re - wi * pc.im;
+        ai = wr * pc.im + wi * pc.re;
+      }
+      re[PTA_FFT_PHYS(t)] = ar;
+      im[PTA_FFT_PHYS(t)] = ai;
+    }
+    __syncthreads();
+    pta_fft_pass<false, 9, TW>(re, im, tw, tid);
   }
-  pta_fft_core<false, 9>(v, tv);
-  pta_fft_store<9>(re, im, b, o, v);
-  pta_wave_sync();
-  pta_fft_pass<false, 6>(re, im, tw, tid);
   __syncthreads();
-  // ---- forward, block pair; the s = 1 butterfly stays in registers through the product with the chirp spectrum (both in
-  // digit-reversed order) and the first inverse butterfly
-  pta_fft_pass<false, 3>(re, im, tw, tid);
-  pta_wave_sync();
-  pta_fft_map<0>(tid, b, o);
-  {
+  pta_fft_pass<false, 6, TW>(re, im, tw, tid);
+  __syncthreads();
+  pta_fft_pass<false, 3, TW>(re, im, tw, tid);
+  __syncthreads();
+  if (FUSE & 1) {
+    int b, o;
+    pta_cplx v[8], fv[8];
+    pta_fft_map<0>(tid, b, o);
     const pta_cplx *fb = reinterpret_cast<const pta_cplx *>(FB) + 8 * b;
-    pta_cplx fv[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) fv[q] = fb[q];
     pta_fft_load<0>(re, im, b, o, v);
@@ -157,100 +175,53 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
 #pragma unroll
     for (int q = 0; q < 8; ++q) v[q] = pta_cmul(v[q], fv[q]);
     pta_dft8<true>(v);
-  }
-  pta_fft_store<0>(re, im, b, o, v);
-  pta_wave_sync();
-  pta_fft_pass<true, 3>(re, im, tw, tid);
-  __syncthreads();
-  // ---- inverse, column pair; the last butterfly's outputs o + 512 q go straight to memory: x_j = Re(post_j * y_j) with
-  // y_j at circular index j - 1, so only indices i0-1 .. i0+npts-2 are stored
-  pta_fft_pass<true, 6>(re, im, tw, tid);
-  pta_wave_sync();
-  pta_fft_map<9>(tid, b, o);
-  pta_fft_twiddles<9>(tw, o, tv);
-  pta_fft_load<9>(re, im, b, o, v);
-  pta_fft_core<true, 9>(v, tv);
-  const pta_cplx *post2 = reinterpret_cast<const pta_cplx *>(post);
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int jj = o + 512 * q - (i0 - 1);
-    if (jj >= 0 && jj < npts) {
-      const pta_cplx pp = post2[jj];
-      G0[(int64_t)row * ldg + jj] = v[q].re * pp.re - v[q].im * pp.im;
-    }
-  }
-}
-
-// Reference structure of the same transform: every pass separated by a workgroup barrier, the draws staged through LDS,
-// the chirp-spectrum product and the output as separate sweeps.  Kept because it is the faster one on MI355X
-//  and as a cross-check of the fused variant.
-// FAST (the opt-in fp32 Box-Muller transcendentals, pta_set_rng_math) is a template parameter: separate kernel names in profiles
-template <bool RNG, bool FAST>
-__global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt_simple(uint64_t seed, uint64_t r0, const double *__restrict__ w, int64_t ldw,
-                                                                int M, int P, int Nf, int npts, int i0,
-                                                                const double *__restrict__ pre, const double *__restrict__ FB,
-                                                                const double *__restrict__ tw, const double *__restrict__ post,
-                                                                double *__restrict__ G0, int64_t ldg) {
-  __shared__ double re[PTA_FFT_PLANE], im[PTA_FFT_PLANE];
-  const int tid = threadIdx.x;
-  const int row = blockIdx.x;
-  const int Kf = Nf - 2;
-  const uint64_t real = r0 + (uint64_t)(row / P);
-  const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(row % P));
-  // chirped, spectrum-weighted draws: A[t] = w[a, t+1] * pre[t]   (pair k = t+1 <-> Re, Im of w[a,k], red_noise.py:240)
-#pragma unroll 1
-  for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {
-    const int t = tid + PTA_FFT_THREADS * i;
-    double ar = 0.0, ai = 0.0;
-    if (t < Kf) {
-      double wr, wi;
-      if (RNG) {
-        pta_normal_pair(seed, real, strm, (uint32_t)(t + 1), wr, wi, FAST ? 1 : 0);
-      } else {
-        wr = w[(int64_t)row * ldw + 2 * (t + 1)];
-        wi = w[(int64_t)row * ldw + 2 * (t + 1) + 1];
-      }
-      const double pr = pre[2 * t], pi_ = pre[2 * t + 1];
-      ar = wr * pr - wi * pi_;
-      ai = wr * pi_ + wi * pr;
-    }
-    re[PTA_FFT_PHYS(t)] = ar;
-    im[PTA_FFT_PHYS(t)] = ai;
-  }
-  __syncthreads();
-  // passes spelled out so that every stride is a compile-time constant
-  pta_fft_pass<false, 9>(re, im, tw, tid);
-  __syncthreads();
-  pta_fft_pass<false, 6>(re, im, tw, tid);
-  __syncthreads();
-  pta_fft_pass<false, 3>(re, im, tw, tid);
-  __syncthreads();
-  pta_fft_pass<false, 0>(re, im, tw, tid);
-  __syncthreads();
+    pta_fft_store<0>(re, im, b, o, v);
+  } else {
+    pta_fft_pass<false, 0, TW>(re, im, tw, tid);
+    __syncthreads();
 #pragma unroll 4
-  for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {  // times the chirp spectrum (both in digit-reversed order)
-    const int t = tid + PTA_FFT_THREADS * i;
-    const int p = PTA_FFT_PHYS(t);
-    const double xr = re[p], xi = im[p], fr = FB[2 * t], fi = FB[2 * t + 1];
-    re[p] = xr * fr - xi * fi;
-    im[p] = xr * fi + xi * fr;
+    for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {
+      const int t = tid + PTA_FFT_THREADS * i;
+      const int p = PTA_FFT_PHYS(t);
+      const double xr = re[p], xi = im[p], fr = FB[2 * t], fi = FB[2 * t + 1];
+      re[p] = xr * fr - xi * fi;
+      im[p] = xr * fi + xi * fr;
+    }
+    __syncthreads();
+    pta_fft_pass<true, 0, TW>(re, im, twi, tid);
   }
   __syncthreads();
-  pta_fft_pass<true, 0>(re, im, tw, tid);
+  pta_fft_pass<true, 3, TW>(re, im, twi, tid);
   __syncthreads();
-  pta_fft_pass<true, 3>(re, im, tw, tid);
+  pta_fft_pass<true, 6, TW>(re, im, twi, tid);
   __syncthreads();
-  pta_fft_pass<true, 6>(re, im, tw, tid);
-  __syncthreads();
-  pta_fft_pass<true, 9>(re, im, tw, tid);
-  __syncthreads();
-  for (int jj = tid; jj < npts; jj += PTA_FFT_THREADS) {  // x_j = Re(post_j * y_j), y_j at circular index j - 1
-    const int p = PTA_FFT_PHYS(i0 - 1 + jj);
-    G0[(int64_t)row * ldg + jj] = re[p] * post[2 * jj] - im[p] * post[2 * jj + 1];
+  const pta_cplx *post2 = reinterpret_cast<const pta_cplx *>(post);
+  if (FUSE & 2) {
+    int b, o;
+    pta_cplx v[8], tv[8];
+    pta_fft_map<9>(tid, b, o);
+    pta_fft_twiddles<9, TW>(twi, o, tv);
+    pta_fft_load<9>(re, im, b, o, v);
+    pta_fft_core<true, 9>(v, tv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int jj = o + 512 * q - (i0 - 1);
+      if (jj >= 0 && jj < npts) {
+        const pta_cplx pp = post2[jj];
+        G0[(int64_t)row * ldg + jj] = v[q].re * pp.re - v[q].im * pp.im;
+      }
+    }
+  } else {
+    pta_fft_pass<true, 9, TW>(re, im, twi, tid);
+    __syncthreads();
+    for (int jj = tid; jj < npts; jj += PTA_FFT_THREADS) {
+      const int p = PTA_FFT_PHYS(i0 - 1 + jj);
+      G0[(int64_t)row * ldg + jj] = re[p] * post2[jj].re - im[p] * post2[jj].im;
+    }
   }
 }
 
-static int g_czt_variant = 0;  // 0 = barrier-per-pass kernel (default, faster), 1 = fused wave-local variant
+static int g_czt_variant = 0;  // 0 = fully fused kernel (default), 1 = plain cross-check (FUSE = 0), 10 + FUSE = any ladder step
 extern "C" int pta_set_czt_variant(int v) {
   g_czt_variant = v;
   return PTA_OK;
@@ -263,35 +234,33 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
   PTA_REQUIRE(pre && FB && tw && post && G0, PTA_E_ARG, "pta_gwb_czt: NULL argument");
   PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && npts > 0 && ldg >= npts, PTA_E_ARG, "pta_gwb_czt: R=%d P=%d npts=%d", R, P, npts);
   PTA_REQUIRE(czt_fits(Nf, npts, i0), PTA_E_ARG, "pta_gwb_czt: Nf=%d npts=%d does not fit one 4096-point convolution", Nf, npts);
-  PTA_REQUIRE(!w || ldw >= 2 * (int64_t)Nf, PTA_E_ARG, "pta_gwb_czt: ldw too small");
+  PTA_REQUIRE(!w || ldw == 0 || ldw >= 2 * (int64_t)Nf, PTA_E_ARG, "pta_gwb_czt: ldw too small");  // 0 = one row of draws for all rows
   int64_t M64 = (int64_t)R * P;
   PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_czt: R*P too large");
   const int M = (int)M64;
   const int fastm = pta_get_rng_fast();
-  if (g_czt_variant == 0) {
-#define PTA_CZT_SIMPLE(RNGV, FASTV)                                                                                                       \
-  hipLaunchKernelGGL((k_gwb_czt_simple<RNGV, FASTV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, \
-                     npts, i0, pre, FB, tw, post, G0, ldg)
-    if (w)
-      PTA_CZT_SIMPLE(false, false);
-    else if (fastm)
-      PTA_CZT_SIMPLE(true, true);
-    else
-      PTA_CZT_SIMPLE(true, false);
-#undef PTA_CZT_SIMPLE
-    PTA_LAUNCH_CHECK();
-    return PTA_OK;
+  const int fuse = g_czt_variant == 0 ? 15 : (g_czt_variant == 1 ? 0 : g_czt_variant - 10);
+#define PTA_CZT_X(RNGV, FASTV, FUSEV)                                                                                                  \
+  hipLaunchKernelGGL((k_gwb_czt<RNGV, FASTV, FUSEV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, \
+                     Nf, npts, i0, pre, FB, tw, post, G0, ldg)
+#define PTA_CZT_XF(FUSEV)              \
+  if (w)                               \
+    PTA_CZT_X(false, false, FUSEV);    \
+  else if (fastm)                      \
+    PTA_CZT_X(true, true, FUSEV);      \
+  else                                 \
+    PTA_CZT_X(true, false, FUSEV)
+  switch (fuse) {
+    case 15: PTA_CZT_XF(15); break;
+    case 0: PTA_CZT_XF(0); break;
+    case 1: PTA_CZT_XF(1); break;
+    case 3: PTA_CZT_XF(3); break;
+    case 7: PTA_CZT_XF(7); break;
+    case 8: PTA_CZT_XF(8); break;
+    default: pta_set_error("pta_gwb_czt: unknown variant %d", g_czt_variant); return PTA_E_ARG;
   }
-  const bool q6 = (Nf - 2) <= 6 * 512;
-#define PTA_CZT_LAUNCH(RNGV, QAV)                                                                                                  \
-  hipLaunchKernelGGL((k_gwb_czt<RNGV, QAV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, Nf, npts, i0, \
-                     pre, FB, tw, post, G0, ldg, fastm)
-  if (w) {
-    if (q6) PTA_CZT_LAUNCH(false, 6); else PTA_CZT_LAUNCH(false, 8);
-  } else {
-    if (q6) PTA_CZT_LAUNCH(true, 6); else PTA_CZT_LAUNCH(true, 8);
-  }
-#undef PTA_CZT_LAUNCH
+#undef PTA_CZT_XF
+#undef PTA_CZT_X
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

@@ -13,8 +13,7 @@
 // Work distribution (512 threads = 8 waves, one radix-8 butterfly per thread per pass).  4096 = 64 x 64: the two
 // long-stride passes (s = 512, 64) only mix the 64 elements of a "column" {o + 64 m}, the two short-stride passes
 // (s = 8, 1) only the 64 elements of a contiguous block.  Wave w owns columns 8w..8w+7 in the first pair and blocks
-// 8w..8w+7 in the second, so inside a pair the hand-over is WAVE-local (LDS ops of one wave execute in order - no
-// workgroup barrier); only the column <-> block transposition between the pairs needs __syncthreads().
+// 8w..8w+7 in the second; with the padding below every pass reads and writes LDS without bank conflicts.
 // All code is per-"thread" work, __host__ __device__, so tests/hostcheck can run it on the CPU.
 #pragma once
 #include "pta_rng.h"  // PTA_HD
@@ -115,13 +114,30 @@ PTA_HD void pta_fft_store(double *re, double *im, int b, int o, const pta_cplx *
   }
 }
 
-// the twiddles of one butterfly, fetched up front so that the loads are in flight while the LDS reads / the RNG run
-template <int LOG2S>
+// the twiddles of one butterfly: w[q] = W^(q m1), W = e^{-2 pi i / 4096}, m1 = o * TSTEP.  Only W^m1, W^2m1 and W^4m1 are
+// loaded (for s = 512 the q-strided gathers of all seven touch up to 56 cache lines per wave and q; these three touch 14);
+// the other four are products - each one rounding (~1e-16) away from the table value.
+template <int LOG2S, int TW = 3>
 PTA_HD void pta_fft_twiddles(const double *tw, int o, pta_cplx *w) {
   const pta_cplx *tw2 = reinterpret_cast<const pta_cplx *>(tw);
   const int m1 = o * pta_fft_stride<LOG2S>::TSTEP;
+  if (LOG2S > 0) {
+    w[1] = tw2[m1];
+    if (TW == 1) {  // one load, squarings: two more roundings on w[4..7]
+      w[2] = pta_cmul(w[1], w[1]);
+      w[4] = pta_cmul(w[2], w[2]);
+    } else {
+      w[2] = tw2[2 * m1];
+      w[4] = tw2[4 * m1];
+    }
+    w[3] = pta_cmul(w[1], w[2]);
+    w[5] = pta_cmul(w[1], w[4]);
+    w[6] = pta_cmul(w[2], w[4]);
+    w[7] = pta_cmul(w[3], w[4]);
+  } else {
 #pragma unroll
-  for (int q = 1; q < 8; ++q) w[q] = (LOG2S > 0) ? tw2[q * m1] : pta_cplx{1.0, 0.0};
+    for (int q = 1; q < 8; ++q) w[q] = pta_cplx{1.0, 0.0};
+  }
 }
 
 // the arithmetic of one butterfly, in registers.  w[q] = e^{-2 pi i o q / (8 s)} from pta_fft_twiddles.
@@ -141,12 +157,12 @@ PTA_HD void pta_fft_core(pta_cplx *v, const pta_cplx *w) {
 }
 
 // load - butterfly - store of one pass for one thread
-template <bool INV, int LOG2S>
+template <bool INV, int LOG2S, int TW = 3>
 PTA_HD void pta_fft_pass(double *re, double *im, const double *tw, int tid) {
   int b, o;
   pta_fft_map<LOG2S>(tid, b, o);
   pta_cplx v[8], w[8];
-  pta_fft_twiddles<LOG2S>(tw, o, w);
+  pta_fft_twiddles<LOG2S, TW>(tw, o, w);
   pta_fft_load<LOG2S>(re, im, b, o, v);
   pta_fft_core<INV, LOG2S>(v, w);
   pta_fft_store<LOG2S>(re, im, b, o, v);

@@ -222,7 +222,7 @@ def test_gwb_idft_rng_equals_replay_of_its_draws(gpu, variant, Nf, npts):
     assert np.max(np.abs(wr[0::2] - z0)) < 1e-13 and np.max(np.abs(wr[1::2] - z1)) < 1e-13
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 11, 13, 17, 18])
 @pytest.mark.parametrize("Nf,npts", [(3000, 600), (3001, 600), (601, 200), (500, 37), (2400, 601), (3400, 600)])
 def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts, variant):
     """chirp-z path: (a) replay form vs numpy's Hermitian-packed ifft; (b) on-chip-RNG form vs the DFT-GEMM over the
