@@ -141,12 +141,13 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 // sums for realisations (l >> 4) + 4 g, TOA (l & 15): exactly the (4 TOAs x 4 realisations) it then finishes on the VALU
 // (GWB interpolation, EFAC/EQUAD and ECORR deviates, deterministic term) and stores as 128-byte row segments.
 #define ENG_MR 16  // realisations per workgroup (MFMA M)
+#define ENG_ZPITCH (2 * PTA_ENGINE_EPMAX + 8)  // = 16 mod 32 doubles: the two realisation rows a half-wave reads sit on disjoint banks
 
 template <bool FAST>
 __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
                                                                            double *__restrict__ out, int64_t ld_out) {
   constexpr int fast = FAST ? 1 : 0;  // template parameter: the two RNG-math modes are separate kernels (and profile rows)
-  __shared__ double zec[ENG_MR][2 * PTA_ENGINE_EPMAX];
+  __shared__ double zec[ENG_MR][ENG_ZPITCH];
   const int tile = blockIdx.y;
   const int rb = blockIdx.x * ENG_MR;
   const int a = pl.tile_psr[tile];
