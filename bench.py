@@ -34,9 +34,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure (not in the local guide)
 # HBM bytes per launch from the PMC passes of the same command (scripts/gpu_profile.sh -> profiles/), KiB as rocprofv3 reports them;
 # FETCH_SIZE is uncorrected (MI355X_MICROARCH.md: it under-counts wide streaming reads by up to 2x on gfx950)
-# insts_valu = SQ_INSTS_VALU (wave instructions) per launch from the same PMC run: the kernel is VALU-issue bound
-PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 969897.0, "write_kib": 2696790.0, "insts_valu": 1.64486e9,
-                                    "source": "profiles/r01_rocprofv3_summary_run37.txt"}}
+# insts_valu = SQ_INSTS_VALU (wave instructions) per launch, valu_busy = VALUBusy from the stall-counter pass of the same
+# summary file: the kernel is VALU-issue bound
+PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 969410.0, "write_kib": 2698390.0, "insts_valu": 1.57235e9, "valu_busy": 0.79,
+                                    "source": "profiles/r01_rocprofv3_summary_run53.txt"}}
 
 
 def headline_array(P=68, N=5000, seed=68):
@@ -299,7 +300,8 @@ def main():
             d["traffic_source"] = t["source"]
             if "insts_valu" in t:   # 4 issue cycles per wave64 VALU instruction, 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
                 issue_ms = t["insts_valu"] * 4.0 / (256 * 4) / 2.4e9 * 1e3
-                d["valu_issue"] = {"insts_valu": t["insts_valu"], "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k]}
+                d["valu_issue"] = {"insts_valu": t["insts_valu"], "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k],
+                                   "valu_busy_pmc": t.get("valu_busy")}   # SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE, same profile
         return d
 
     def flop_roof(k):
