@@ -169,6 +169,7 @@ int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R,
 
 /* G[r,a,:] = sum_b Mchol[a,b] G0[r,b,:]  (the M@w of red_noise.py:268, applied after the DFT). */
 int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream);
+int pta_set_mix_variant(int variant); /* 0 (default): LDS-resident Mchol kernel when P <= 80; 1: always the generic batched GEMM */
 
 /* jlo[i] = last j with ut[j] <= toa_s[i], clamped to [0, npts-2] (numpy.interp's bracket, which
  * scipy.interpolate.interp1d(kind="linear") delegates to; red_noise.py:286-287).           */

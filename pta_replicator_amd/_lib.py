@@ -65,6 +65,7 @@ _SIGNATURES = {
     "pta_gwb_twiddle_sym": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P]),
     "pta_gwb_idft_rng": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, c_int, _P, c_int64, _P]),
     "pta_set_czt_variant": (c_int, [c_int]),
+    "pta_set_mix_variant": (c_int, [c_int]),
     "pta_gwb_czt_fits": (c_int, [c_int, c_int, c_int]),
     "pta_gwb_czt_setup": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P]),
     "pta_gwb_czt": (c_int, [c_uint64, c_uint64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),

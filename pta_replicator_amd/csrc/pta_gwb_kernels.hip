@@ -271,10 +271,88 @@ extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf
 }
 
 // ---- mix: G[r] = Mchol . G0[r]  (red_noise.py:268, moved behind the DFT) -------------------------
+// Array-sized specialisation (P <= 80): the generic 64x64-tile GEMM spends half its matrix-core work and a second read of
+// G0 on the 4 rows that 68 pulsars spill into a second tile.  Here Mchol sits in LDS K-major (lane <-> pulsar, conflict
+// free), every wave owns 16 grid samples and all ceil(P/16) pulsar tiles, G0 rows stream in as the B operand straight from
+// global memory (128-byte segments) and each workgroup amortises the LDS fill over `rpw` realisations.  HBM bound:
+// 16 bytes per (realisation, pulsar, sample).
+#define MIX_JT 64
+template <int NTA>
+__global__ __launch_bounds__(256) void k_gwb_mix_small(const double *__restrict__ Mchol, int P, const double *__restrict__ G0, int R,
+                                                       int npts, int64_t ldg, double *__restrict__ G, int rpw) {
+  extern __shared__ double Ms[];  // [KP][MP]: Ms[b * MP + a] = Mchol[a][b], zero padded
+  constexpr int MP = NTA * 16;
+  const int KP = (P + 3) & ~3;
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  for (int idx = t; idx < KP * MP; idx += 256) {
+    const int b = idx / MP, a = idx - b * MP;
+    Ms[idx] = (a < P && b < P) ? Mchol[(int64_t)a * P + b] : 0.0;
+  }
+  __syncthreads();
+  const int col = l & 15, quad = l >> 4;
+  const int jj = blockIdx.x * MIX_JT + wv * 16 + col;
+  const bool jin = jj < npts;
+  for (int rr = 0; rr < rpw; ++rr) {
+    const int r = blockIdx.y * rpw + rr;
+    if (r >= R) break;
+    const double *__restrict__ g0 = G0 + (int64_t)r * P * ldg;
+    pta_f64x4 acc[NTA];
+#pragma unroll
+    for (int i = 0; i < NTA; ++i) acc[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    double bv[NTA * 4];  // all K-steps' G0 samples of this realisation in flight at once (KP / 4 <= NTA * 4)
+#pragma unroll
+    for (int s4 = 0; s4 < NTA * 4; ++s4) {
+      const int b = 4 * s4 + quad;
+      bv[s4] = (b < P && jin) ? g0[(int64_t)b * ldg + jj] : 0.0;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < NTA * 4; ++s4) {
+      if (4 * s4 < KP) {  // uniform
+        const int b = 4 * s4 + quad;
+#pragma unroll
+        for (int i = 0; i < NTA; ++i) acc[i] = pta_mfma_f64(Ms[b * MP + i * 16 + col], bv[s4], acc[i]);
+      }
+    }
+    if (jin) {
+#pragma unroll
+      for (int i = 0; i < NTA; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int a = i * 16 + pta_mfma_row(l, rg);
+          if (a < P) G[((int64_t)r * P + a) * ldg + jj] = acc[i][rg];
+        }
+    }
+  }
+}
+
+static int g_mix_variant = 0;  // 0 = specialised kernel when P <= 80, 1 = always the generic batched GEMM
+extern "C" int pta_set_mix_variant(int v) {
+  g_mix_variant = v;
+  return PTA_OK;
+}
+
 extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream) {
   PTA_REQUIRE(Mchol && G0 && G, PTA_E_ARG, "pta_gwb_mix: NULL argument");
   PTA_REQUIRE(P > 0 && R > 0 && npts > 0 && ldg >= npts, PTA_E_ARG, "pta_gwb_mix: P=%d R=%d npts=%d", P, R, npts);
   const int64_t sr = (int64_t)P * ldg;
+  if (g_mix_variant == 0 && P <= 80) {
+    const int nta = (P + 15) / 16, kp = (P + 3) & ~3;
+    const int rpw = 4;
+    const size_t shmem = (size_t)kp * nta * 16 * sizeof(double);
+    dim3 g(pta_cdiv(npts, MIX_JT), pta_cdiv(R, rpw));
+    PTA_REQUIRE(g.y <= 65535u, PTA_E_ARG, "pta_gwb_mix: R=%d too large for one launch", R);
+#define PTA_MIX(N) hipLaunchKernelGGL(k_gwb_mix_small<N>, g, dim3(256), shmem, pta_stream(stream), Mchol, P, G0, R, npts, ldg, G, rpw)
+    switch (nta) {
+      case 1: PTA_MIX(1); break;
+      case 2: PTA_MIX(2); break;
+      case 3: PTA_MIX(3); break;
+      case 4: PTA_MIX(4); break;
+      default: PTA_MIX(5); break;
+    }
+#undef PTA_MIX
+    PTA_LAUNCH_CHECK();
+    return PTA_OK;
+  }
   for (int rb = 0; rb < R; rb += 32768) {
     int rc_ = (R - rb < 32768) ? (R - rb) : 32768;
     int rc = pta_dgemm_launch(0, P, npts, P, 1.0, Mchol, P, 1, G0 + rb * sr, ldg, 0.0, G + rb * sr, ldg, 0, rc_, 0, sr, sr,

@@ -29,4 +29,9 @@ for var in (0, 6, 0, 6):
     res.setdefault(f"v{var}_ms", []).append(round(ms, 4))
     res[f"v{var}_maxdiff"] = float((o - ref).abs().max())
 _lib.call("pta_set_synth_variant", 0)
+npts, P = eng.plan.gw_npts, eng.P
+for mv in (0, 1, 0, 1):
+    _lib.call("pta_set_mix_variant", mv)
+    res.setdefault(f"mix{mv}_ms", []).append(round(timed(lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s)), 4))
+_lib.call("pta_set_mix_variant", 0)
 print(json.dumps(res))

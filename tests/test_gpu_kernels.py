@@ -298,3 +298,26 @@ def test_td_mode_against_oracle(gpu):
     lib.call("pta_td_trmm", dv.ptr(L), N, N, dv.ptr(z_d), N, R, dv.ptr(out), N, 0, gpu["s"])
     ref = po.td_draw(Cref, z.T).T
     assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-8 * np.sqrt(np.mean(ref ** 2))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("P,npts,R,ldg", [(68, 600, 5, 600), (3, 50, 1, 50), (16, 64, 9, 64), (17, 65, 4, 72), (80, 601, 3, 608), (81, 100, 2, 100),
+                                          (200, 120, 2, 120), (1, 7, 6, 7)])
+def test_gwb_mix_against_numpy(gpu, P, npts, R, ldg, variant):
+    """G[r] = Mchol @ G0[r] (red_noise.py:268 behind the transform): the LDS-resident specialisation (P <= 80) and the generic
+    batched GEMM, ragged sizes and a padded leading dimension."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    rng = np.random.default_rng(P * 1000 + npts)
+    M = np.tril(rng.standard_normal((P, P)))
+    G0 = rng.standard_normal((R, P, ldg))
+    M_d, G0_d = dv.f64(M), dv.f64(G0)
+    G_d = dv.f64(np.full((R, P, ldg), 7.0))
+    lib.call("pta_set_mix_variant", variant)
+    try:
+        lib.call("pta_gwb_mix", dv.ptr(M_d), P, dv.ptr(G0_d), R, npts, ldg, dv.ptr(G_d), gpu["s"])
+    finally:
+        lib.call("pta_set_mix_variant", 0)
+    G = G_d.cpu().numpy()
+    ref = np.einsum("ab,rbj->raj", M, G0[:, :, :npts])
+    assert np.max(np.abs(G[:, :, :npts] - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
+    assert np.all(G[:, :, npts:] == 7.0)            # padding columns untouched
