@@ -179,7 +179,8 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
     const int ra = min(rb + col, R - 1);
     const double *__restrict__ cf = pl.rn_coef + ((int64_t)ra * P + a) * K;
     const double *__restrict__ Fb = pl.Ft + start;
-    for (int k0 = 0; k0 < K; k0 += 4) {
+#pragma unroll 5
+    for (int k0 = 0; k0 < K; k0 += 4) {  // unrolled so that several K-steps' loads are in flight (4 waves per SIMD hide little)
       const int k = k0 + quad;
       const bool kin = k < K;
       const double av = kin ? cf[k] : 0.0;

@@ -96,6 +96,21 @@ def test_config4_headline_array_with_cgw():
         ref = po.cgw_dt(a.mjd[p], np.pi / 2 - dec, ra, **cw)
         assert relrms(det[a.off[p]:a.off[p + 1]], ref) < 5e-10
     _fused_equals_replay(a, 2)
+    # one GPU's share of the config (2048 of the 16384 realisations, rank 3's range): batch == one-by-one, finite, and the
+    # ensemble variance of one pulsar's residuals is stationary across the shard
+    import torch
+    from pta_replicator_amd.distributed import shard_range
+    lo, hi = shard_range(16384, rank=3, world=8)
+    assert (lo, hi) == (6144, 8192)
+    big = a.generate(hi - lo, r0=lo)
+    assert big.shape == (2048, a.n_toa) and bool(torch.isfinite(big).all())
+    for r in (0, 1000, 2047):
+        assert torch.equal(big[r], a.generate(1, r0=lo + r)[0])
+    sel = big[:, a.off[5]:a.off[6]] - a.d_det[a.off[5]:a.off[6]]
+    v1, v2 = float(sel[:1024].var()), float(sel[1024:].var())
+    assert abs(v1 / v2 - 1) < 0.2
+    del big, sel
+    torch.cuda.empty_cache()
 
 
 def test_config5_ska_scale_anisotropic():
