@@ -335,7 +335,7 @@ def main():
     td = None
     if not args.no_td and world == 1:
         try:
-            td = td_mode_numbers(args.toa, 8, 512)
+            td = td_mode_numbers(args.toa, args.psr, 512)   # the whole array: 68 x 5000^2 fp64 = 13.6 GB of covariance
         except Exception as e:  # pragma: no cover
             td = {"error": str(e)}
 

@@ -108,13 +108,27 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
 #define HBM_T 128
 #define HLD 144  // == 16 (mod 32)
 
-template <bool BT>
+// VEC (needs BT, ska == 1, even K, 16-byte aligned rows): the operand slabs are fetched as double2 with 16 lanes on 16
+// rows and the four quads on consecutive k pairs - 16 cache lines per wave load.  The scalar pattern (one row per lane, eight
+// strided 8-byte loads) touches 64 lines per load and kept the kernel L1/TA-bound at ~60 % MFMA utilisation.
+template <bool BT, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                           int64_t lda, int64_t ska, const double *__restrict__ B,
                                                           int64_t ldb, double beta, double *__restrict__ C, int64_t ldc,
                                                           int lower_only, int64_t sA, int64_t sB, int64_t sC) {
-  const int bm = blockIdx.y, bn = blockIdx.x;
-  if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) return;
+  int bm = blockIdx.y, bn = blockIdx.x;
+  if (lower_only == 2) {
+    // square lower-triangular update launched over its nt (nt + 1) / 2 tiles only: tile t <-> (bm, bn), bn <= bm, row by row.
+    // Besides skipping the empty workgroups this keeps the 8 XCDs (workgroups are dealt round-robin) evenly loaded - with a
+    // 2-D grid whose width is a multiple of 8 every XCD owns fixed tile columns and the first ones carry 1.5x the work.
+    const int tix = blockIdx.x;
+    bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+    while (bm * (bm + 1) / 2 > tix) --bm;
+    bn = tix - bm * (bm + 1) / 2;
+  } else if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) {
+    return;
+  }
   A += (int64_t)blockIdx.z * sA;
   B += (int64_t)blockIdx.z * sB;
   C += (int64_t)blockIdx.z * sC;
@@ -132,7 +146,24 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
   // A slab: 128 rows x 16 k, 8 consecutive k per thread.  B slab: [N x K] -> same pattern; [K x N] -> 16 k-rows x 8 n
   const int a_row = t >> 1, a_kq = (t & 1) * 8;
   const int b_kr = t >> 4, b_nq = (t & 15) * 8;
+  const int v_row = w * 32 + (l & 15), v_kp = l >> 4;  // VEC: rows v_row + 16 g, k pairs v_kp + 4 h
   auto fetch = [&](int k0) {
+    if (VEC) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int gm = m0 + v_row + 16 * g, gn = n0 + v_row + 16 * g, gk = k0 + 2 * (v_kp + 4 * h);
+          double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+          if (gm < M && gk < K) va = *reinterpret_cast<const double2 *>(A + (int64_t)gm * lda + gk);
+          if (gn < N && gk < K) vb = *reinterpret_cast<const double2 *>(B + (int64_t)gn * ldb + gk);
+          ra[4 * g + 2 * h] = va.x;
+          ra[4 * g + 2 * h + 1] = va.y;
+          rb[4 * g + 2 * h] = vb.x;
+          rb[4 * g + 2 * h + 1] = vb.y;
+        }
+      return;
+    }
     int gm = m0 + a_row;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -156,6 +187,18 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
     }
   };
   auto stash = [&](int buf) {
+    if (VEC) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            As[buf][2 * (v_kp + 4 * h) + e][v_row + 16 * g] = ra[4 * g + 2 * h + e];
+            Bs[buf][2 * (v_kp + 4 * h) + e][v_row + 16 * g] = rb[4 * g + 2 * h + e];
+          }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) As[buf][a_kq + j][a_row] = ra[j];
     if (BT) {
@@ -242,10 +285,19 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
   } else if (algo == 1 && M >= 256 && N >= 128 && K >= 32) {  // large operands: 128x128 tiles
     PTA_REQUIRE(pta_cdiv(M, HBM_T) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
     dim3 g(pta_cdiv(N, HBM_T), pta_cdiv(M, HBM_T), batch);
-    if (transB)
-      hipLaunchKernelGGL(k_dgemm_mfma128<true>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    if (lower_only && M == N) {
+      const unsigned nt = pta_cdiv(M, HBM_T);
+      g = dim3(nt * (nt + 1) / 2, 1, batch);
+      lower_only = 2;
+    }
+    const bool vec = transB && ska == 1 && (K % 2) == 0 && (lda % 2) == 0 && (ldb % 2) == 0 && (sA % 2) == 0 && (sB % 2) == 0 &&
+                     ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
+    if (vec)
+      hipLaunchKernelGGL((k_dgemm_mfma128<true, true>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    else if (transB)
+      hipLaunchKernelGGL((k_dgemm_mfma128<true, false>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else
-      hipLaunchKernelGGL(k_dgemm_mfma128<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+      hipLaunchKernelGGL((k_dgemm_mfma128<false, false>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
   } else {
     PTA_REQUIRE(pta_cdiv(M, GBM) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
     dim3 g(pta_cdiv(N, GBN), pta_cdiv(M, GBM), batch);

@@ -71,49 +71,76 @@ extern "C" int pta_orf_combine(const double *basis, const double *clm, int nbasi
 #define CH_NB 64
 #define CH_LD 65
 
+// Factor the diagonal block AND invert the factor in the same 64-step sweep, the 64 x 64 tile held in REGISTERS (16 elements
+// per thread: rows ti + 16 a, columns tc + 16 b).  Tile layout: L below the diagonal, the pivot d_j on it (sqrt(d_j) goes to
+// D), and X^T above it, X = L^{-1} (forward substitution in its right-looking form: once row j of X is final,
+// X[i][:] -= L[i][j] X[j][:] for i > j).  With col[x] = r * tile(x, j), r = 1 / sqrt(d_j), step j is, for every position
+// (p, q) with q > j:
+//     p >= q  (Schur complement of L)  or  p < j  (X[q][p])  :  tile(p, q) -= col[p] * col[q]
+//     p == j                           (X[q][j] = -L[q][j] / L[j][j]) :  tile(j, q)  = -col[q] * r
+// and column j itself is scaled by r.  The owners of column j publish it (unscaled) through a double-buffered LDS vector:
+// ONE barrier per step, no serial section.  The tile leaves as the MFMA panel solve wants it (L below, X^T above; X's
+// diagonal 1 / L[j][j] is recomputed by the consumer).
 __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, int k0, int nb, int32_t *__restrict__ info) {
-  __shared__ double S[CH_NB][CH_LD];
-  __shared__ double djj;
-  double *M = A + (int64_t)blockIdx.x * n * n;
-  const int t = threadIdx.x;
-  for (int i = t >> 6; i < nb; i += 4)
-    for (int c = t & 63; c < nb; c += 64) S[i][c] = (c <= i) ? M[(int64_t)(k0 + i) * n + (k0 + c)] : 0.0;
-  for (int j = 0; j < nb; ++j) {
-    __syncthreads();
-    if (t == 0) {
-      double d = S[j][j];
-      if (!(d > 0.0) && info[blockIdx.x] == 0) info[blockIdx.x] = k0 + j + 1;  // LAPACK: leading minor j+1 not PD
-      d = sqrt(d);
-      S[j][j] = d;
-      djj = d;
+  __shared__ double colbuf[2][CH_NB];
+  double *M = A + (int64_t)blockIdx.x * n * n + (int64_t)k0 * n + k0;
+  const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
+  double v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int p = ti + 16 * a, q = tc + 16 * b;
+      v[a][b] = (p < nb && q <= p) ? M[(int64_t)p * n + q] : 0.0;
     }
-    __syncthreads();
-    double inv = 1.0 / djj;
-    for (int i = j + 1 + t; i < nb; i += 256) S[i][j] = S[i][j] * inv;
-    __syncthreads();
-    // rank-1 update of the trailing lower triangle; threads as a 16 x 16 grid striding the block (no divisions)
-    for (int i = j + 1 + (t >> 4); i < nb; i += 16) {
-      const double lij = S[i][j];
-      for (int c = j + 1 + (t & 15); c <= i; c += 16) S[i][c] = fma(-lij, S[c][j], S[i][c]);
+#pragma unroll
+  for (int jq = 0; jq < 4; ++jq) {
+    for (int jr = 0; jr < 16; ++jr) {
+      const int j = 16 * jq + jr;
+      if (j >= nb) break;  // uniform
+      double *cb = colbuf[j & 1];
+      if (tc == jr) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cb[ti + 16 * a] = v[a][jq];
+      }
+      __syncthreads();
+      const double d = cb[j];
+      double r = __builtin_amdgcn_rsq(d);  // 1/sqrt(d): hardware seed + two Newton steps
+      r = r * fma(-0.5 * d * r, r, 1.5);
+      r = r * fma(-0.5 * d * r, r, 1.5);
+      double cp[4], cq[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) cp[a] = cb[ti + 16 * a] * r;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) cq[b] = cb[tc + 16 * b] * r;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int p = ti + 16 * a, q = tc + 16 * b;
+          if (q > j) {
+            if (p >= q || p < j)
+              v[a][b] = fma(-cp[a], cq[b], v[a][b]);
+            else if (p == j)
+              v[a][b] = -cq[b] * r;
+          } else if (q == j) {
+            if (p != j)
+              v[a][b] = cp[a];        // column j scaled
+            else {
+              if (!(d > 0.0) && info[blockIdx.x] == 0) info[blockIdx.x] = k0 + j + 1;  // LAPACK: leading minor j+1 not PD
+              v[a][b] = d * r;        // L[j][j] = sqrt(d)
+            }
+          }
+        }
     }
   }
-  __syncthreads();
-  // inverse of the factored block for the MFMA panel solve: column j of L^{-1} by forward substitution, one thread per
-  // column.  Its strictly lower part is parked TRANSPOSED in the strict upper triangle of the block (free until
-  // k_zero_upper clears it); its diagonal is 1/diag(L) and is recomputed by the consumer.
-  __shared__ double T[CH_NB][CH_LD];
-  if (t < nb) {
-    const int j = t;
-    T[j][j] = 1.0 / S[j][j];
-    for (int i = j + 1; i < nb; ++i) {
-      double acc = 0.0;
-      for (int q = j; q < i; ++q) acc = fma(S[i][q], T[q][j], acc);
-      T[i][j] = -acc / S[i][i];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int p = ti + 16 * a, q = tc + 16 * b;
+      if (p < nb && q < nb) M[(int64_t)p * n + q] = v[a][b];
     }
-  }
-  __syncthreads();
-  for (int i = t >> 6; i < nb; i += 4)
-    for (int c = t & 63; c < nb; c += 64) M[(int64_t)(k0 + i) * n + (k0 + c)] = (c <= i) ? S[i][c] : T[c][i];
 }
 
 __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int k0, int nb) {

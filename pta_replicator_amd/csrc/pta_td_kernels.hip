@@ -17,8 +17,12 @@ __global__ __launch_bounds__(256) void k_td_cov(const double *__restrict__ Ft, i
                                                 const double *__restrict__ phi, const double *__restrict__ sigma2,
                                                 const int32_t *__restrict__ epoch_of, const double *__restrict__ ecorr2,
                                                 double *__restrict__ C, int64_t ldc) {
-  const int bm = blockIdx.y, bn = blockIdx.x;
-  if (bn > bm) return;
+  // launched over the nt (nt + 1) / 2 lower-triangular tiles only, row by row: no empty workgroups, XCDs evenly loaded
+  const int tix = blockIdx.x;
+  int bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+  while (bm * (bm + 1) / 2 > tix) --bm;
+  const int bn = tix - bm * (bm + 1) / 2;
   __shared__ double As[TBK][TLD];
   __shared__ double Bs[TBK][TLD];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -77,7 +81,8 @@ extern "C" int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, 
   PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble: ecorr2 missing");
   PTA_REQUIRE(N > 0 && K > 0 && ldf >= N && ldc >= N && pta_cdiv(N, TBM) <= 65535u, PTA_E_ARG, "pta_td_cov_assemble: N=%d K=%d", N, K);
   unsigned nt = pta_cdiv(N, TBM);
-  hipLaunchKernelGGL(k_td_cov, dim3(nt, nt), dim3(256), 0, pta_stream(stream), Ft, ldf, N, K, phi, sigma2, epoch_of, ecorr2, C, ldc);
+  hipLaunchKernelGGL(k_td_cov, dim3(nt * (nt + 1) / 2), dim3(256), 0, pta_stream(stream), Ft, ldf, N, K, phi, sigma2, epoch_of, ecorr2, C,
+                     ldc);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
