@@ -155,7 +155,7 @@ int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const dou
  * (Nf-2) + npts - 2 < 4096 (pta_gwb_czt_fits): x_j = (2/(n dt)) Re(W^{j^2/2} sum_k (sqrtC_k w_k W^{k^2/2}) W^{-(j-k)^2/2}),
  * one circular convolution of length 4096 per (realisation, pulsar) row = two in-LDS radix-8 fp64 FFTs,
  * ~0.5 MFLOP per row instead of 3.6 MFLOP of dense DFT.  pta_gwb_czt_setup fills pre[2*4096] (pre-chirp with
- * sqrtC), FB[2*4096] (chirp spectrum / 4096, digit-reversed order), tw[2*4096] (FFT twiddles), post[2*npts].
+ * sqrtC), FB[2*4096] (chirp spectrum / 4096, digit-reversed order, stored [q][b] per 8-point butterfly b), tw[2*4096] (FFT twiddles), post[2*npts].
  * pta_gwb_czt: w == NULL draws on chip (stream (GWB, a), pair k, like pta_gwb_idft_rng), else w[R*P x ldw]
  * interleaved (re, im) rows as in pta_gwb_idft (ldw = 0: one row of draws shared by all rows - timing probe).  */
 int pta_gwb_czt_fits(int Nf, int npts, int i0);

@@ -67,8 +67,11 @@ __global__ __launch_bounds__(PTA_FFT_THREADS) void k_czt_setup(const double *__r
   pta_fft_pass<false, 0>(re, im, tw, tid);
   __syncthreads();
   for (int m = tid; m < PTA_FFT_N; m += PTA_FFT_THREADS) {  // logical (digit-reversed) order, 1/L of the inverse folded in
-    FB[2 * m] = re[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
-    FB[2 * m + 1] = im[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
+    // stored butterfly-transposed: element q of the s = 1 butterfly b (logical index 8 b + q) at [q][b], so that the eight
+    // loads of the fused kernel are 1 KB-contiguous per wave instead of 64 lanes x 128-byte stride
+    const int slot = (m & 7) * (PTA_FFT_N / 8) + (m >> 3);
+    FB[2 * slot] = re[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
+    FB[2 * slot + 1] = im[PTA_FFT_PHYS(m)] * (1.0 / PTA_FFT_N);
   }
 }
 
@@ -167,9 +170,9 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
     int b, o;
     pta_cplx v[8], fv[8];
     pta_fft_map<0>(tid, b, o);
-    const pta_cplx *fb = reinterpret_cast<const pta_cplx *>(FB) + 8 * b;
+    const pta_cplx *fb = reinterpret_cast<const pta_cplx *>(FB) + b;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) fv[q] = fb[q];
+    for (int q = 0; q < 8; ++q) fv[q] = fb[q * (PTA_FFT_N / 8)];
     pta_fft_load<0>(re, im, b, o, v);
     pta_dft8<false>(v);
 #pragma unroll
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
     for (int i = 0; i < PTA_FFT_N / PTA_FFT_THREADS; ++i) {
       const int t = tid + PTA_FFT_THREADS * i;
       const int p = PTA_FFT_PHYS(t);
-      const double xr = re[p], xi = im[p], fr = FB[2 * t], fi = FB[2 * t + 1];
+      const int slot = (t & 7) * (PTA_FFT_N / 8) + (t >> 3);
+      const double xr = re[p], xi = im[p], fr = FB[2 * slot], fi = FB[2 * slot + 1];
       re[p] = xr * fr - xi * fi;
       im[p] = xr * fi + xi * fr;
     }

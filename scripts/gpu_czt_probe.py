@@ -21,7 +21,7 @@ def timed(fn, reps=5):
 
 out = {}
 ref = None
-for var in (0, 10, 18, 13, 17, 25, 17, 25, 10, 18):
+for var in (0, 1, 0, 1, 25):
     try:
         _lib.call("pta_set_czt_variant", var)
         out[f"v{var}_full_ms"] = timed(lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, s))
