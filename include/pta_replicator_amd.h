@@ -255,7 +255,8 @@ int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r
  * C[i,j] = sum_c phi[c] Ft[c,i] Ft[c,j] + (i==j) sigma2[i] + (epoch_of[i]==epoch_of[j]) ecorr2[i]
  * i.e. the covariance of the reference's RN (red_noise.py:98-101,126-128) + WN/ECORR
  * (white_noise.py:105-109,182) synthesis.  Only the lower triangle (col <= row) is written - that is
- * all pta_potrf_batched reads.  HBM-write bound: 8 bytes per element of the triangle.        */
+ * all pta_potrf_batched reads.  HBM traffic: 8 bytes per element of the triangle, written once; at K = 60 the
+ * rank-K product costs 16.6 flop per byte, so the fp64 matrix rate, not HBM, bounds it.      */
 int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const double *phi, const double *sigma2,
                         const int32_t *epoch_of, const double *ecorr2, double *C, int64_t ldc, void *stream);
 
