@@ -249,6 +249,27 @@ int pta_set_synth_variant(int min_waves_per_simd);
 int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
                      void *stream);
 
+/* One call = R whole-array realisations: pta_engine_rn_coef -> pta_gwb_czt (or pta_gwb_idft_rng) -> pta_gwb_mix ->
+ * pta_engine_synth on `stream`, with plan->rn_coef / plan->gw_G taken from the workspace below.  The batched
+ * counterpart of one pass of the reference's add_gwb + add_red_noise + add_measurement_noise + add_jitter (+ add_cgw)
+ * over the array (red_noise.py:106-298, white_noise.py:47-198).                                            */
+typedef struct {
+  const double *rn_amp;       /* [n_psr x rn_k] sqrt(prior), red_noise.py:126 (NULL when rn_k == 0) */
+  const double *Mchol;        /* [n_psr x n_psr] Cholesky factor of the ORF (NULL when gw_npts == 0) */
+  int32_t gw_nf;              /* Nf of the GWB frequency grid */
+  int32_t gw_i0;              /* crop offset (10, red_noise.py:285) */
+  int32_t use_czt;            /* 1: chirp-z tables below; 0: Tsym / rot of the DFT-GEMM form */
+  int32_t reserved;
+  const double *czt_pre, *czt_FB, *czt_tw, *czt_post; /* from pta_gwb_czt_setup */
+  const double *Tsym, *rot;   /* from pta_gwb_twiddle_sym */
+  double *ws_coef;            /* [R x n_psr x rn_k] */
+  double *ws_G0;              /* [R x n_psr x gw_npts] per-pulsar grid series */
+  double *ws_G;               /* [R x n_psr x gw_npts] mixed grid series */
+} pta_engine_tables;
+
+int pta_engine_generate(const pta_engine_plan *plan_host, const pta_engine_tables *tables_host, uint64_t seed, uint64_t r0, int R,
+                        double *out, int64_t ld_out, void *stream);
+
 /* ---------------------------------------------------------------- TD mode ---------- */
 /* Dense time-domain path named by BASELINE.json's north_star (no counterpart in the reference,
  * which never forms an N_toa x N_toa object: SURVEY.md §0.2, App. A.1).

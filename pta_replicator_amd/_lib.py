@@ -41,6 +41,15 @@ class EnginePlan(ctypes.Structure):
     ]
 
 
+class EngineTables(ctypes.Structure):
+    """pta_engine_tables (include/pta_replicator_amd.h)."""
+    _fields_ = [
+        ("rn_amp", _P), ("Mchol", _P), ("gw_nf", c_int32), ("gw_i0", c_int32), ("use_czt", c_int32), ("reserved", c_int32),
+        ("czt_pre", _P), ("czt_FB", _P), ("czt_tw", _P), ("czt_post", _P), ("Tsym", _P), ("rot", _P),
+        ("ws_coef", _P), ("ws_G0", _P), ("ws_G", _P),
+    ]
+
+
 _SIGNATURES = {
     "pta_abi_version": (c_int, []),
     "pta_last_error": (c_char_p, []),
@@ -78,6 +87,7 @@ _SIGNATURES = {
     "pta_cw_catalog": (c_int, [_P, c_int, _P, c_int, _P, _P, c_double, c_int, c_double, c_int, c_int, c_double, _P, _P, _P, c_int, _P]),
     "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, _P]),
     "pta_set_synth_variant": (c_int, [c_int]),
+    "pta_engine_generate": (c_int, [POINTER(EnginePlan), POINTER(EngineTables), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),

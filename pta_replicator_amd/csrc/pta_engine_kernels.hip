@@ -288,3 +288,40 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
+
+extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
+                           const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
+                           void *stream);
+extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot, int npts,
+                                double *G0, int64_t ldg, void *stream);
+extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream);
+
+extern "C" int pta_engine_generate(const pta_engine_plan *plan_host, const pta_engine_tables *tables_host, uint64_t seed, uint64_t r0,
+                                   int R, double *out, int64_t ld_out, void *stream) {
+  PTA_REQUIRE(plan_host && tables_host && out, PTA_E_ARG, "pta_engine_generate: NULL argument");
+  pta_engine_plan p = *plan_host;
+  const pta_engine_tables &tb = *tables_host;
+  int rc;
+  if (p.rn_k > 0) {
+    PTA_REQUIRE(tb.rn_amp && tb.ws_coef, PTA_E_ARG, "pta_engine_generate: red-noise amplitudes / workspace missing");
+    rc = pta_engine_rn_coef(seed, r0, R, p.n_psr, p.rn_k, tb.rn_amp, tb.ws_coef, stream);
+    if (rc != PTA_OK) return rc;
+    p.rn_coef = tb.ws_coef;
+  }
+  if (p.gw_npts > 0) {
+    PTA_REQUIRE(tb.Mchol && tb.ws_G0 && tb.ws_G, PTA_E_ARG, "pta_engine_generate: GWB factor / workspace missing");
+    if (tb.use_czt) {
+      PTA_REQUIRE(tb.czt_pre && tb.czt_FB && tb.czt_tw && tb.czt_post, PTA_E_ARG, "pta_engine_generate: chirp-z tables missing");
+      rc = pta_gwb_czt(seed, r0, nullptr, 0, R, p.n_psr, tb.gw_nf, p.gw_npts, tb.gw_i0, tb.czt_pre, tb.czt_FB, tb.czt_tw, tb.czt_post,
+                       tb.ws_G0, p.gw_npts, stream);
+    } else {
+      PTA_REQUIRE(tb.Tsym && tb.rot, PTA_E_ARG, "pta_engine_generate: DFT-GEMM tables missing");
+      rc = pta_gwb_idft_rng(seed, r0, R, p.n_psr, tb.gw_nf, tb.Tsym, tb.rot, p.gw_npts, tb.ws_G0, p.gw_npts, stream);
+    }
+    if (rc != PTA_OK) return rc;
+    rc = pta_gwb_mix(tb.Mchol, p.n_psr, tb.ws_G0, R, p.gw_npts, p.gw_npts, tb.ws_G, stream);
+    if (rc != PTA_OK) return rc;
+    p.gw_G = tb.ws_G;
+  }
+  return pta_engine_synth(&p, seed, r0, R, out, ld_out, stream);
+}

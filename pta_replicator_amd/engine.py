@@ -110,6 +110,7 @@ class ReplicaEngine:
     # ---------------------------------------------------------------- prepare -------------------
     def prepare(self):
         dev = dv.require_gpu()
+        self._ws = None  # tables of a previous prepare() point at replaced buffers
         s = dv.stream_ptr()
         P, N = self.P, self.n_toa
         self.d_psr_of = dv.i32(np.repeat(np.arange(P), self.counts))
@@ -320,41 +321,42 @@ class ReplicaEngine:
 
     # ---------------------------------------------------------------- throughput mode -----------
     def workspace(self, R):
-        """device buffers for a batch of R realisations (reused across generate() calls)."""
+        """device buffers for a batch of R realisations (reused across generate() calls) and the pta_engine_tables that
+        point at them."""
         ws = getattr(self, "_ws", None)
         if ws is None or ws["R"] < R:
             ws = {"R": R}
+            tb = _lib.EngineTables()
             if self.plan.rn_k:
                 ws["coef"] = dv.empty((R, self.P, self.K))
+                tb.rn_amp, tb.ws_coef = self.d_amp.data_ptr(), ws["coef"].data_ptr()
             if self.plan.gw_npts:
                 ws["G0"] = dv.empty((R, self.P, self.plan.gw_npts))
                 ws["G"] = dv.empty((R, self.P, self.plan.gw_npts))
+                tb.Mchol, tb.ws_G0, tb.ws_G = self.d_M.data_ptr(), ws["G0"].data_ptr(), ws["G"].data_ptr()
+                tb.gw_nf, tb.gw_i0, tb.use_czt = self.grid["Nf"], 10, 1 if self.use_czt else 0
+                if self.use_czt:
+                    tb.czt_pre, tb.czt_FB, tb.czt_tw, tb.czt_post = (x.data_ptr() for x in self.d_czt)
+                tb.Tsym, tb.rot = self.d_Tsym.data_ptr(), self.d_rot.data_ptr()
+            ws["tables"] = tb
             self._ws = ws
         return ws
 
     def generate(self, R, r0=0, out=None):
-        """out[R, n_toa] (device tensor, seconds): realisations r0 .. r0+R-1, every deviate drawn on chip."""
+        """out[R, n_toa] (device tensor, seconds): realisations r0 .. r0+R-1, every deviate drawn on chip: one call of
+        pta_engine_generate (coefficients -> GWB transform -> mix -> fused synthesis, all queued on the current stream)."""
         if not self._prepared:
             self.prepare()
-        s = dv.stream_ptr()
         if out is None:
             out = dv.empty((R, self.n_toa))
         ws = self.workspace(R)
-        pl = self.plan
-        if pl.rn_k:
-            _lib.call("pta_engine_rn_coef", self.seed, r0, R, self.P, self.K, dv.ptr(self.d_amp), dv.ptr(ws["coef"]), s)
-            pl.rn_coef = ws["coef"].data_ptr()
-        if pl.gw_npts:
-            npts = pl.gw_npts
-            if self.use_czt:
-                _lib.call("pta_gwb_czt", self.seed, r0, None, 0, R, self.P, self.grid["Nf"], npts, 10,
-                          *[dv.ptr(x) for x in self.d_czt], dv.ptr(ws["G0"]), npts, s)
-            else:
-                _lib.call("pta_gwb_idft_rng", self.seed, r0, R, self.P, self.grid["Nf"], dv.ptr(self.d_Tsym), dv.ptr(self.d_rot), npts,
-                          dv.ptr(ws["G0"]), npts, s)
-            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), self.P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s)
-            pl.gw_G = ws["G"].data_ptr()
-        _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(out), out.stride(0), s)
+        _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0, R, dv.ptr(out),
+                  out.stride(0), dv.stream_ptr())
+        # per-kernel callers (bench.py, replay) read the workspace pointers from the plan
+        if self.plan.rn_k:
+            self.plan.rn_coef = ws["coef"].data_ptr()
+        if self.plan.gw_npts:
+            self.plan.gw_G = ws["G"].data_ptr()
         return out
 
     # ---------------------------------------------------------------- replay mode ---------------
