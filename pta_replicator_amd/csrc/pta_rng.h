@@ -93,15 +93,27 @@ PTA_HD void pta_uniform_pair(pta_u32x4 v, double &u1, double &u2) {
 
 // x/y and sqrt(x) without the IEEE division / square-root expansions: those lean on VCC (v_div_scale ->
 // v_div_fmas) and on long fix-up tails, which serialises the eight independent Box-Muller chains a thread of the
-// fused kernel keeps in flight.  Hardware reciprocal / reciprocal-sqrt seeds (~2^-23) + two Newton steps + one
+// fused kernel keeps in flight.  Hardware reciprocal / reciprocal-sqrt seeds (~2^-23) + one Newton step + one exact-
 // residual correction: < 1 ulp for the well-scaled arguments used here.  The host twins are the plain operators.
+// fma(x, p, c) with a compile-time constant addend.  Left to itself the compiler turns a Horner step into v_mov_b64 (constant ->
+// accumulator) + v_fmac_f64; the three-source form reads the constant from a scalar register pair instead: one VALU
+// instruction per step (11 fewer per Box-Muller pair).  The host twin is plain fma - identical rounding.
+PTA_HD double pta_fma_k(double x, double p, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(p), "s"(c));
+  return d;
+#else
+  return fma(x, p, c);
+#endif
+}
+
 PTA_HD double pta_div(double x, double y) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(y);
-  r = fma(fma(-y, r, 1.0), r, r);
-  r = fma(fma(-y, r, 1.0), r, r);
+  double r = __builtin_amdgcn_rcp(y);      // relative error ~2^-23
+  r = fma(fma(-y, r, 1.0), r, r);          // ~2^-46
   double q = x * r;
-  return fma(fma(-y, q, x), r, q);
+  return fma(fma(-y, q, x), r, q);         // exact residual x - y q, corrected with the 2^-46 reciprocal: error ~2^-92 + rounding
 #else
   return x / y;
 #endif
@@ -111,13 +123,10 @@ PTA_HD double pta_sqrt_pos(double x) {  // x >= 0; exact zero is nudged to 1e-30
   x = fmax(x, 1e-300);
   double r = __builtin_amdgcn_rsq(x);
   double g = x * r, h = 0.5 * r;
-  double d = fma(-h, g, 0.5);
+  double d = fma(-h, g, 0.5);              // one coupled Newton step: g ~ sqrt(x), h ~ 1/(2 sqrt(x)) to ~2^-46
   g = fma(g, d, g);
   h = fma(h, d, h);
-  d = fma(-h, g, 0.5);
-  g = fma(g, d, g);
-  h = fma(h, d, h);
-  return fma(fma(-g, g, x), h, g);
+  return fma(fma(-g, g, x), h, g);         // exact residual x - g^2, corrected: error ~2^-92 + rounding
 #else
   return sqrt(fmax(x, 1e-300));
 #endif
@@ -142,8 +151,8 @@ PTA_HD double pta_neg2log(double u) {
   double f = m - 1.0;
   double s = pta_div(f, 2.0 + f);
   double z = s * s, w = z * z;
-  double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-  double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+  double t1 = w * pta_fma_k(w, fma(w, Lg6, Lg4), Lg2);
+  double t2 = z * pta_fma_k(w, pta_fma_k(w, fma(w, Lg7, Lg5), Lg3), Lg1);
   double R = t2 + t1;
   double hfsq = 0.5 * f * f;
   double dk = (double)e;
@@ -162,9 +171,9 @@ PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
   double r = u - 0.25 * q;         // [-1/8, 1/8], exact
   double x = 6.283185307179586 * r;
   double z = x * x;
-  double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+  double ps = pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, fma(z, S6, S5), S4), S3), S2), S1);
   double s = fma(x * z, ps, x);
-  double pc = z * fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+  double pc = z * pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, fma(z, C6, C5), C4), C3), C2), C1);
   double c = 1.0 - (0.5 * z - z * pc);
   int k = (int)q & 3;
   double s1 = (k & 1) ? c : s;
@@ -174,7 +183,8 @@ PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
 }
 
 // Box-Muller: (z0, z1) iid N(0,1).
-// fast = 0 (default): fp64 transform, every step < 1 ulp (the deviates are reproducible on the host to ~1e-16).
+// fast = 0 (default): fp64 transform, every step < 1 ulp; the deviates sit within 3 ulp of an 80-bit evaluation of the same
+//           uniforms (scripts/gpu_rng_accuracy.py, 2^21 deviates) and are reproducible on the host to ~1e-16.
 // fast = 1 ("fast RNG math", opt-in): the SAME uniforms through the hardware fp32 transcendentals (v_log_f32, v_sqrt_f32,
 //           v_sin_f32 / v_cos_f32, which take their argument in turns) - deviates accurate to ~1e-6, a statistically
 //           irrelevant perturbation of a random number, at 40 % of the instructions.  Signal arithmetic stays fp64.
