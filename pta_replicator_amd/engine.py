@@ -359,6 +359,41 @@ class ReplicaEngine:
             self.plan.gw_G = ws["G"].data_ptr()
         return out
 
+    def stream_to_host(self, total, chunk=480, r0=0):
+        """Generator over (first_realisation, host_array[n, n_toa]) covering realisations r0 .. r0+total-1: generation on
+        the current stream, device->host copies of the previous chunk on a second stream into two pinned buffers, so the
+        PCIe link (2.72 MB per realisation at 68 x 5000) is the only thing waited for.  The yielded array is a view of a
+        pinned buffer that is reused two chunks later - copy it if it must outlive the next two iterations."""
+        if not self._prepared:
+            self.prepare()
+        chunk = int(min(chunk, total))
+        dev = [dv.empty((chunk, self.n_toa)) for _ in range(2)]
+        host = [torch.empty((chunk, self.n_toa), dtype=torch.float64).pin_memory() for _ in range(2)]
+        copy_stream = torch.cuda.Stream()
+        filled = [torch.cuda.Event(), torch.cuda.Event()]   # generation of buffer b finished
+        copied = [torch.cuda.Event(), torch.cuda.Event()]   # its copy to the host finished
+        main = torch.cuda.current_stream()
+        pending = []                                        # (buffer, first realisation, count) copies in flight
+        done = 0
+        while done < total or pending:
+            if done < total:
+                b = (done // chunk) & 1
+                n = min(chunk, total - done)
+                if done >= 2 * chunk:
+                    main.wait_event(copied[b])              # the device buffer is free again
+                self.generate(n, r0=r0 + done, out=dev[b][:n])
+                filled[b].record(main)
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(filled[b])
+                    host[b][:n].copy_(dev[b][:n], non_blocking=True)
+                    copied[b].record(copy_stream)
+                pending.append((b, r0 + done, n))
+                done += n
+            if len(pending) == 2 or done >= total:
+                b, first, n = pending.pop(0)
+                copied[b].synchronize()
+                yield first, host[b][:n].numpy()
+
     # ---------------------------------------------------------------- replay mode ---------------
     def dump_draws(self, r):
         """The normals realisation r uses in generate(), as NumPy arrays in the reference's shapes:
