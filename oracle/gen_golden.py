@@ -24,6 +24,7 @@ variants.npz     the branches the shipped vector does not pin: t
                  default RN convention, every add_cgw branch.
 c3_mini.npz      a 6-pulsar miniature of config 3 (HD GWB + RN + EFAC/EQUAD + ECORR, notebook seeds).
 cw_catalog.npz   add_catalog_of_cws through both numba kernels of the reference (40 and 1200 sources).
+rn_modes.npz     add_red_noise(modes=...) in both phase conventions.
 transients.npz   add_burst / add_noise_transient / add_gw_memory with Gaussian-sine waveforms.
 population.npz   add_gwb_plus_outlier_cws on a 1500-binary synthetic population (userSpec GWB + 22 outlier CWs).
 """
@@ -445,6 +446,22 @@ def gen_transients(ref):
     print("transients:", {k: float(np.sqrt(np.mean(out[k] ** 2))) for k in ("burst", "burst_quad", "noise_transient", "gw_memory")})
 
 
+def gen_rn_modes(ref):
+    """add_red_noise with an explicit `modes` frequency list (red_noise.py:64-66,119-121; `components` is then ignored), both
+    phase conventions."""
+    psrs, mjd0 = synth_array(ref, 2, 180, seed=555, burst=1, backends=("X",))
+    out = pulsar_inputs("", psrs, mjd0)
+    modes = np.array([1.0, 2.0, 3.0, 5.0, 8.0, 13.0]) / (5478 * 86400.0)
+    out["modes"] = modes
+    for tag, conv in (("default", False), ("libstempo", True)):
+        ps, _ = synth_array(ref, 2, 180, seed=555, burst=1, backends=("X",))
+        for a, p in enumerate(ps):
+            ref.red_noise.add_red_noise(p, -13.3, 3.7, components=30, seed=4242 + a, modes=modes, libstempo_convention=conv)
+        out["rn_" + tag] = np.array([sig(p, "red_noise") for p in ps])
+    np.savez_compressed(os.path.join(OUT, "rn_modes.npz"), **out)
+    print("rn_modes: rms", float(np.sqrt(np.mean(out["rn_default"] ** 2))))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = rr.load_reference()
@@ -456,5 +473,6 @@ if __name__ == "__main__":
     gen_cw_catalog(ref)
     gen_population(ref)
     gen_transients(ref)
+    gen_rn_modes(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -270,3 +270,13 @@ def test_td_oracle_covariance_matches_synthesis_statistics():
     U = (epoch_of[:, None] == np.arange(ne)[None, :]).astype(float)
     ref = F @ np.diag(phi) @ F.T + np.diag(sig2) + (U * ec ** 2) @ U.T
     assert np.max(np.abs(Cm - ref)) < 1e-12 * np.max(np.abs(ref))
+
+
+def test_red_noise_explicit_modes():
+    """add_red_noise(modes=...) (red_noise.py:64-66,119-128): `components` is ignored, 2 len(modes) deviates are drawn."""
+    z = load("rn_modes.npz")
+    for tag, conv in (("default", False), ("libstempo", True)):
+        for i in range(2):
+            (zr,) = po.legacy_normals(4242 + i, [2 * len(z["modes"])])
+            dt = po.red_noise_dt(mjd_ld(z, "", i), -13.3, 3.7, zr, components=30, libstempo_convention=conv, modes=z["modes"])
+            assert relrms(dt, z["rn_" + tag][i]) < TOL, (tag, i)
