@@ -58,3 +58,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text.replace("oracle/pta_oracle.py", "").replace("(oracle/", "("), f
+
+
+def test_header_is_plain_c(tmp_path):
+    """the boundary is a C ABI: the header must compile as C99 (and as C++) without any HIP / torch include"""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "pta_replicator_amd.h"\nint main(void){ pta_engine_plan p; pta_engine_tables t; (void)p; (void)t; return PTA_OK; }\n')
+    for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            pytest.skip(cc + " not available")
+        r = subprocess.run([cc, *flags, "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
