@@ -242,7 +242,8 @@ typedef struct {
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
 int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, void *stream);
 
-/* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs per workgroup);
+/* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs per workgroup), workgroups
+ * dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same kernel in plain linear workgroup order (A/B);
  * 4 / 6 / 8 = all-VALU kernel compiled for that many waves per SIMD (kept for cross-checks)     */
 int pta_set_synth_variant(int min_waves_per_simd);
 

@@ -145,11 +145,18 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 
 template <bool FAST>
 __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_engine_plan pl, uint64_t seed, uint64_t r0, int R,
-                                                                           double *__restrict__ out, int64_t ld_out) {
+                                                                           double *__restrict__ out, int64_t ld_out, int xcd_aware) {
   constexpr int fast = FAST ? 1 : 0;  // template parameter: the two RNG-math modes are separate kernels (and profile rows)
   __shared__ double zec[ENG_MR][ENG_ZPITCH];
-  const int tile = blockIdx.y;
-  const int rb = blockIdx.x * ENG_MR;
+  // 1-D launch, XCD-aware: hardware deals consecutive workgroups round-robin to the 8 XCDs, so workgroup `lin` is given the
+  // work item (lin % 8) * chunk + lin / 8 - each XCD walks its own contiguous range of (tile, realisation group) items and a
+  // tile's design-matrix slab and per-TOA vectors live in ONE L2 instead of eight.
+  const int nrg = (R + ENG_MR - 1) / ENG_MR;
+  const int64_t total = (int64_t)nrg * pl.n_tiles, chunk = (total + 7) >> 3;
+  const int64_t item = xcd_aware ? (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  if (item >= total) return;
+  const int tile = (int)(item / nrg);
+  const int rb = (int)(item - (int64_t)tile * nrg) * ENG_MR;
   const int a = pl.tile_psr[tile];
   const int start = pl.tile_start[tile];
   const int count = pl.tile_count[tile];
@@ -266,13 +273,16 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
   PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed one launch", p.n_tiles);
-  if (g_synth_minw == 0) {
+  if (g_synth_minw == 0 || g_synth_minw == 1) {  // 1: same kernel, plain linear workgroup order (A/B of the XCD mapping)
+    const int xcd = g_synth_minw == 0 ? 1 : 0;
+    const int64_t total = (int64_t)pta_cdiv(R, ENG_MR) * p.n_tiles, nwg = ((total + 7) >> 3) << 3;
+    PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_engine_synth: %lld workgroups exceed one launch", (long long)nwg);
     if (pta_get_rng_fast())
-      hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed,
-                         r0, R, out, ld_out);
+      hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R, out,
+                         ld_out, xcd);
     else
-      hipLaunchKernelGGL(k_engine_synth_mfma<false>, dim3(pta_cdiv(R, ENG_MR), p.n_tiles), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed,
-                         r0, R, out, ld_out);
+      hipLaunchKernelGGL(k_engine_synth_mfma<false>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R, out,
+                         ld_out, xcd);
     PTA_LAUNCH_CHECK();
     return PTA_OK;
   }
