@@ -36,8 +36,8 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure
 # FETCH_SIZE is uncorrected (MI355X_MICROARCH.md: it under-counts wide streaming reads by up to 2x on gfx950)
 # insts_valu = SQ_INSTS_VALU (wave instructions) per launch, valu_busy = VALUBusy from the stall-counter pass of the same
 # summary file: the kernel is VALU-issue bound
-PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 972876.0, "write_kib": 2710400.0, "insts_valu": 1.43518e9, "valu_busy": 0.753,
-                                    "source": "profiles/r01_rocprofv3_summary_run72.txt"}}
+PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 361309.0, "write_kib": 2669630.0, "insts_valu": 1.44648e9, "valu_busy": 0.769,
+                                    "source": "profiles/r01_rocprofv3_summary_run81.txt"}}
 
 
 def headline_array(P=68, N=5000, seed=68):
