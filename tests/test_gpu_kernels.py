@@ -132,7 +132,7 @@ def test_orf_kernels_vs_reference_golden(gpu):
     assert np.max(np.abs(orf2 - 2 * sum(clm[k] * ref[k] for k in range(4)))) < 1e-13
 
 
-@pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (64, 1), (68, 1), (130, 4), (200, 2), (515, 1)])
+@pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (64, 1), (68, 1), (130, 4), (200, 2), (515, 1), (512, 2), (1000, 1), (1338, 3)])
 def test_potrf_batched_vs_numpy(gpu, n, batch):
     from pta_replicator_amd import red_noise as rn
     dv, lib = gpu["dv"], gpu["lib"]
