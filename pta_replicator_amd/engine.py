@@ -359,6 +359,39 @@ class ReplicaEngine:
             self.plan.gw_G = ws["G"].data_ptr()
         return out
 
+    def generate_per_signal(self, R, r0=0):
+        """{'rn', 'gwb', 'wn', 'ecorr', 'det', 'total'}: the same realisations as generate(R, r0), one [R, n_toa] array per
+        signal (the batched counterpart of the reference's per-signal ``added_signals_time`` entries).  Every deviate is a pure
+        function of (seed, realisation, stream, index), so running the fused kernel once per signal with the other inputs
+        switched off reproduces exactly the deviates of the combined pass."""
+        if not self._prepared:
+            self.prepare()
+        total = self.generate(R, r0=r0)                      # also fills the workspace (coefficients, mixed GWB grid series)
+        pl, s = self.plan, dv.stream_ptr()
+        keep = (pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det)
+        out = {"total": total}
+        try:
+            def one(name, **on):
+                pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = (
+                    on.get("rn_k", 0), on.get("gw_npts", 0), on.get("wn_a"), on.get("wn_b"), on.get("ecorr_toa"),
+                    on.get("epoch_of"), on.get("det"))
+                buf = dv.empty((R, self.n_toa))
+                _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(buf), buf.stride(0), s)
+                out[name] = buf
+            if keep[0]:
+                one("rn", rn_k=keep[0])
+            if keep[1]:
+                one("gwb", gw_npts=keep[1])
+            if keep[2]:
+                one("wn", wn_a=keep[2], wn_b=keep[3])
+            if keep[4]:
+                one("ecorr", ecorr_toa=keep[4], epoch_of=keep[5])
+            if keep[6]:
+                out["det"] = self.d_det.unsqueeze(0).expand(R, self.n_toa)
+        finally:
+            pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = keep
+        return out
+
     def stream_to_host(self, total, chunk=480, r0=0):
         """Generator over (first_realisation, host_array[n, n_toa]) covering realisations r0 .. r0+total-1: generation on
         the current stream, device->host copies of the previous chunk on a second stream into two pinned buffers, so the
