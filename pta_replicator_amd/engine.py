@@ -349,9 +349,12 @@ class ReplicaEngine:
             self.prepare()
         if out is None:
             out = dv.empty((R, self.n_toa))
-        ws = self.workspace(R)
-        _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0, R, dv.ptr(out),
-                  out.stride(0), dv.stream_ptr())
+        step = 65536                                        # launch-grid limits of the mix / fused kernels; also bounds the workspace
+        ws = self.workspace(min(R, step))
+        for lo in range(0, R, step):
+            n = min(step, R - lo)
+            _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0 + lo, n,
+                      ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)), out.stride(0), dv.stream_ptr())
         # per-kernel callers (bench.py, replay) read the workspace pointers from the plan
         if self.plan.rn_k:
             self.plan.rn_coef = ws["coef"].data_ptr()
@@ -366,6 +369,8 @@ class ReplicaEngine:
         switched off reproduces exactly the deviates of the combined pass."""
         if not self._prepared:
             self.prepare()
+        if R > 65536:
+            raise ValueError("generate_per_signal: at most 65536 realisations per call")
         total = self.generate(R, r0=r0)                      # also fills the workspace (coefficients, mixed GWB grid series)
         pl, s = self.plan, dv.stream_ptr()
         keep = (pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det)
