@@ -182,12 +182,15 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
   const int rows = min(CH_NB, n - r0);
   for (int i = t >> 6; i < CH_NB; i += 4)
     for (int c = t & 63; c < CH_NB; c += 64) {
+      // tile element (i, c) of the factored diagonal block, read along its row (coalesced): above the diagonal it is
+      // (L11^{-1})[c][i] (parked transposed by k_potf2) and goes to Li[c][i]; on it, 1 / L[i][i]; below, Li[c][i] = 0
       double v = 0.0;
       if (i < nb && c < nb) {
-        if (c < i) v = M[(int64_t)(k0 + c) * n + (k0 + i)];        // parked transposed in the upper triangle
-        else if (c == i) v = 1.0 / M[(int64_t)(k0 + i) * n + (k0 + i)];
+        const double m = M[(int64_t)(k0 + i) * n + (k0 + c)];
+        if (c > i) v = m;
+        else if (c == i) v = 1.0 / m;
       }
-      Li[i][c] = v;
+      Li[c][i] = v;
       X[i][c] = (i < rows && c < nb) ? M[(int64_t)(r0 + i) * n + (k0 + c)] : 0.0;
     }
   __syncthreads();
