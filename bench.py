@@ -29,7 +29,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GW_LOG10_A = -14.6733          # noise_dicts/ng15_dict.json "gw_log10_A" 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure (not in the local guide)
 # HBM bytes per launch from the PMC passes of the same command (scripts/gpu_profile.sh -> profiles/), KiB as rocprofv3 reports them;
@@ -40,37 +39,58 @@ PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 3613
                                     "source": "profiles/r01_rocprofv3_summary_run81.txt"}}
 
 
+def ng15_noise():
+    """per-pulsar, per-backend noise values of the reference's noise_dicts/ng15_dict.json (fixture written by
+    oracle/gen_ng15_fixture.py; the dictionary itself does not travel to the GPU box)."""
+    with open(os.path.join(ROOT, "tests", "golden", "ng15_noise.json")) as fh:
+        return json.load(fh)
+
+
 def headline_array(P=68, N=5000, seed=68):
-    """Config 3 of BASELINE.json as synthetic inputs: isotropic sky, sorted uniform MJDs over
-    15 yr, 0.5 us errors, per-pulsar power-law RN (one pulsar without, like J0614-3329), EFAC/EQUAD/ECORR."""
+    """BASELINE.json config 3 as SURVEY.md §8d specifies it: the 68 pulsars of ng15_dict.json (names, per-backend
+    EFAC / t2EQUAD / ECORR, red noise of the 67 pulsars that have it, gw_log10_A), on synthetic inputs where the reference
+    ships none - isotropic sky (RAJ ~ U(0, 24) h, sin DEC ~ U(-1, 1), default_rng(68)), N sorted TOAs ~ U(53000, 58478) MJD,
+    0.5 us errors, every TOA tagged with one of its pulsar's backends (flag "f").  P != 68 cycles through the dictionary."""
     from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    nd = ng15_noise()
+    names = list(nd["pulsars"])
     rng = np.random.default_rng(seed)
     raj = rng.uniform(0, 24, P)
     decj = np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
     psrs = []
+    noise = dict(flags=[], efac=[], log10_equad=[], log10_ecorr=[], rn_log10_A=[], rn_gamma=[], gw_log10_A=float(nd["gw_log10_A"]))
     for a in range(P):
+        name = names[a % len(names)]
+        rec = nd["pulsars"][name]
         mjd = np.sort(rng.uniform(53000, 58478, N))
-        psr = SimulatedPulsar(toas=ArrayTOAs(mjd, 0.5), name=f"J{a:04d}+0000", loc={"RAJ": float(raj[a]), "DECJ": float(decj[a])})
+        be = rec["backends"]
+        which = rng.integers(0, len(be), N)
+        psr = SimulatedPulsar(toas=ArrayTOAs(mjd, 0.5, flags=[{"f": be[k]} for k in which]),
+                              name=name if a < len(names) else f"{name}_{a // len(names)}", loc={"RAJ": float(raj[a]), "DECJ": float(decj[a])})
         make_ideal(psr)
         psrs.append(psr)
-    rn_A = [float(x) for x in rng.uniform(-15.0, -13.0, P)]
-    rn_g = [float(x) for x in rng.uniform(1.0, 5.0, P)]
-    if P > 7:
-        rn_A[7] = rn_g[7] = None
-    noise = dict(rn_log10_A=rn_A, rn_gamma=rn_g, efac=[float(x) for x in rng.uniform(0.9, 1.2, P)],
-                 log10_equad=[float(x) for x in rng.uniform(-7.0, -6.0, P)],
-                 log10_ecorr=[float(x) for x in rng.uniform(-7.0, -6.0, P)], gw_log10_A=GW_LOG10_A)
+        noise["flags"].append(list(be))
+        noise["efac"].append(np.array([1.0 if v is None else v for v in rec["efac"]]))   # one backend has no EFAC entry: the default
+        noise["log10_equad"].append(np.array(rec["log10_t2equad"]))
+        noise["log10_ecorr"].append(np.array(rec["log10_ecorr"]))
+        noise["rn_log10_A"].append(rec["red_noise_log10_A"])                              # None for J0614-3329
+        noise["rn_gamma"].append(rec["red_noise_gamma"])
     return psrs, noise
+
+
+def configure_engine(eng, noise):
+    """GWB (HD, gamma = 13/3) + per-pulsar power-law RN (30 components) + per-backend EFAC / t2EQUAD / ECORR (0.1 d epochs)."""
+    eng.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"], flags=noise["flags"])
+    eng.set_jitter(log10_ecorr=noise["log10_ecorr"], flags=noise["flags"], coarsegrain=0.1)
+    eng.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"], components=30)
+    eng.set_gwb(noise["gw_log10_A"], 13. / 3.)
+    return eng
 
 
 def build_engine(P, N, seed):
     from pta_replicator_amd.engine import ReplicaEngine
     psrs, noise = headline_array(P, N)
-    eng = ReplicaEngine(psrs, seed=seed)
-    eng.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"])
-    eng.set_jitter(log10_ecorr=noise["log10_ecorr"], coarsegrain=0.1)
-    eng.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"], components=30)
-    eng.set_gwb(noise["gw_log10_A"], 13. / 3.)
+    eng = configure_engine(ReplicaEngine(psrs, seed=seed), noise)
     eng.prepare()
     return eng, psrs, noise
 

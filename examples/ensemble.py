@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from bench import headline_array                      # synthetic array with the NANOGrav 15-yr noise dictionary's shape
+from bench import configure_engine, headline_array                      # synthetic array with the NANOGrav 15-yr noise dictionary's shape
 from pta_replicator_amd.distributed import generate_sharded
 from pta_replicator_amd.engine import ReplicaEngine
 
@@ -20,10 +20,7 @@ if world > 1:
 
 psrs, noise = headline_array(68, 5000)
 eng = ReplicaEngine(psrs, seed=2026)
-eng.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"])
-eng.set_jitter(log10_ecorr=noise["log10_ecorr"], coarsegrain=0.1)
-eng.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"], components=30)
-eng.set_gwb(noise["gw_log10_A"], 13.0 / 3.0)
+configure_engine(eng, noise)   # per-backend EFAC / EQUAD / ECORR, per-pulsar RN, HD GWB: values of ng15_dict.json
 eng.prepare()
 
 # this rank's share of 4096 realisations, resident on its GPU: [n_local, 340000] seconds

@@ -45,7 +45,7 @@ int pta_device_info(int *cu_count, int *wavefront, char *arch, int arch_len);
 /* Throughput-mode draws. The reference consumes NumPy's global legacy stream
  * (red_noise.py:119,127,176,238-240; white_noise.py:80,105-109,155,182); on the device every
  * deviate is Philox-4x32-10(key = seed, counter = (pair, stream, realisation)) + Box-Muller.
- * stream ids: (kind << 24) | pulsar, kind = 1 GWB, 2 RN, 3 WN, 4 ECORR, 5 TD.           */
+ * stream ids: (kind << 24) | pulsar, kind = 1 GWB, 2 RN, 3 WN, 4 ECORR, 5 TD (N_a x N_a factor), 6 TDGW (GWB grid factor). */
 
 /* Gaussian transform used by every on-chip draw (process-wide): 0 (default) = fp64 Box-Muller with < 1 ulp log / sincos,
  * 1 = "fast RNG math": the same uniforms through the hardware fp32 log / sqrt / sin / cos (deviates accurate to ~1e-6).  */
@@ -114,6 +114,20 @@ int pta_orf_combine(const double *basis, const double *clm, int nbasis, int P, d
  * leading minor of order j+1 is not positive definite (LAPACK convention).  Blocked right-looking:
  * LDS panel factorisation + fp64 MFMA (v_mfma_f64_16x16x4_f64) trailing update.             */
 int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
+
+/* The same factorisation for matrices with a leading dimension and a batch stride: matrix b is row-major at A + b * strideA
+ * with row pitch lda >= n.  flags: PTA_POTRF_ZERO_UPPER zeroes the strict upper triangle (np.linalg.cholesky's result);
+ * without it the upper triangle is left holding scratch (the parked inverses of the diagonal blocks) - all TD mode needs,
+ * since pta_td_trmm_rng reads the lower triangle only.  For n > 512 the schedule uses look-ahead: the next panel is factored
+ * on an internal high-priority stream while the bulk of the trailing update runs on a second internal stream (both created on
+ * first use and joined back into `stream` before returning; results are identical); PTA_POTRF_NO_LOOKAHEAD keeps every
+ * launch on `stream` (A/B timing).                                                                                  */
+#define PTA_POTRF_ZERO_UPPER 1
+#define PTA_POTRF_NO_LOOKAHEAD 2
+#define PTA_POTRF_SUBSTITUTION 4  /* panel solves by forward substitution instead of the MFMA product with the inverted diagonal
+                                     block: LAPACK-grade backward error also when the diagonal blocks are very ill-conditioned
+                                     (cond(L11) * eps enters the product form) - used for the GWB grid covariance, cond ~ 3e14 */
+int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 /* debug/validation knob: 1 (default) = MFMA GEMM inside potrf / mix / trmm, 0 = VALU reference GEMM */
 int pta_set_gemm_algo(int algo);
@@ -287,6 +301,42 @@ int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const doubl
  * pta_rng_fill_normal(stream (TD, pulsar)) in throughput mode.                              */
 int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld_z, int R, double *out, int64_t ld_out,
                 int accumulate, void *stream);
+
+/* Throughput form of the same draw: Z is never materialised - every lane GENERATES its MFMA A operand in registers
+ * (stream kind PTA_STREAM_TD / PTA_STREAM_TDGW, deviate j of row m = pair j >> 1, branch j & 1), so one launch covers all
+ * pulsars:   out[m, blk_off[b] + i] = sum_{j <= i} L_b[i, j] z(m, b, j)  (+ GWB interpolation + deterministic delay).
+ *   rows_per_real == 1 : row m = realisation r0 + m, factor block b = pulsar b, stream (stream_kind, b)   (per-pulsar N_a x N_a factors)
+ *   rows_per_real == P : ONE factor block shared by all rows; row m = (realisation r0 + m / P, pulsar m % P), stream
+ *                        (stream_kind, m % P)   (the npts x npts factor of the GWB grid covariance)
+ * Factor b is row-major at Lbase + blk_pos[b] with leading dimension blk_ld[b]; blk_pos and blk_ld must be EVEN (16-byte
+ * double2 loads) and only elements on or below the diagonal are read (pta_potrf_batched_ex may leave the upper triangle
+ * unzeroed).  Work items = strips of PTA_TD_STRIP consecutive rows of one factor, sorted by the caller by decreasing
+ * min(n, n0 + PTA_TD_STRIP) (their K extent) so that the long strips start first.
+ * Optional epilogue (rows_per_real == 1 only): gw_G[(m * n_blocks + b) * gw_npts + j] is the mixed GWB grid series of
+ * (realisation m, pulsar b), interpolated with gw_jlo / gw_w exactly as pta_engine_synth does (red_noise.py:286-287);
+ * det is added to every row.  All three are indexed by OUTPUT column.                                              */
+#define PTA_TD_STRIP 256
+typedef struct {
+  const double *Lbase;
+  const int64_t *blk_pos;     /* [n_blocks] element offset of factor b inside Lbase (even) */
+  const int32_t *blk_ld;      /* [n_blocks] leading dimension (even, >= blk_n) */
+  const int32_t *blk_n;       /* [n_blocks] order of factor b */
+  const int32_t *blk_off;     /* [n_blocks] first output column of block b */
+  const int32_t *item_blk;    /* [n_items] factor block of the strip */
+  const int32_t *item_n0;     /* [n_items] first row of the strip (multiple of PTA_TD_STRIP) */
+  int32_t n_blocks;
+  int32_t n_items;
+  int32_t rows_per_real;
+  uint32_t stream_kind;       /* 5 = PTA_STREAM_TD, 6 = PTA_STREAM_TDGW */
+  int32_t rng_fast;           /* 0 = fp64 Box-Muller (default), 1 = fp32 transcendentals; per call, not process-wide */
+  int32_t gw_npts;
+  const double *gw_G;         /* NULL = no GWB epilogue */
+  const int32_t *gw_jlo;
+  const double *gw_w;
+  const double *det;          /* NULL = none */
+} pta_td_plan;
+
+int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out, void *stream);
 
 /* ---------------------------------------------------------------- fp64 GEMM -------- */
 /* C[b] = alpha * A[b] * op(B[b]) + beta * C[b], row-major, batch `batch` with element strides.

@@ -591,3 +591,52 @@ def td_covariance(toas_s, log10_amplitude, spectral_index, components, sigma2_wn
 def td_draw(Cm, z):
     """L z with L = cholesky(C) lower; z is [N] or [N, R]."""
     return np.linalg.cholesky(Cm) @ z
+
+
+def td_gwb_grid_covariance(grid, C, i0=10):
+    """Covariance of the npts grid samples Res_t[a, i0:i0+npts] of ONE pulsar with unit ORF, implied by the reference's
+    frequency-domain synthesis (red_noise.py:265-285):
+        Sigma[p, q] = 4 / (dt^2 n^2) * sum_{k=1..Nf-2} C_k cos(2 pi k (p - q) / n),   n = 2 Nf - 2
+    (w_k = x + i y with x, y ~ N(0,1); DC and Nyquist bins zeroed, :271-272).  Toeplitz in (p - q); the crop offset i0 drops
+    out.  Between pulsars a, b the covariance is ORF_ab * Sigma (the mix with M = cholesky(ORF), :235,268)."""
+    Nf, npts, dt = grid["Nf"], grid["npts"], grid["dt"]
+    n = 2 * Nf - 2
+    k = np.arange(1, Nf - 1)
+    lag = np.arange(npts)
+    col = 4.0 / (dt ** 2 * n ** 2) * (np.cos(2 * np.pi * np.outer(lag, k) / n) @ C[1:Nf - 1])
+    idx = np.abs(lag[:, None] - lag[None, :])
+    return col[idx]
+
+
+def cholesky_longdouble(S):
+    """reference-quality lower Cholesky factor in x87 extended precision (64-bit mantissa), outer-product form: the yardstick
+    against which the forward error of a float64 factorisation (LAPACK's or the device's) is measured when the matrix is
+    too ill-conditioned for two float64 factorisations to agree with each other."""
+    A = np.array(S, dtype=np.longdouble)
+    n = A.shape[0]
+    L = np.zeros_like(A)
+    for j in range(n):
+        d = A[j, j]
+        if not d > 0:
+            raise np.linalg.LinAlgError(f"leading minor {j + 1} not positive definite")
+        r = np.sqrt(d)
+        L[j, j] = r
+        col = A[j + 1:, j] / r
+        L[j + 1:, j] = col
+        A[j + 1:, j + 1:] -= np.outer(col, col)
+    return L
+
+
+def td_realisation(toa_s_list, td_cov_list, z_td, grid=None, Lg=None, M=None, z_gw=None, det=None):
+    """one TD-mode realisation on the CPU: per pulsar cholesky(C_a) @ z_a (+ the GWB term: grid series Lg @ z_gw[a] per
+    pulsar, mixed with M = cholesky(ORF) and interpolated onto the TOAs like red_noise.py:268,286-287) (+ det)."""
+    P = len(td_cov_list)
+    out = [td_draw(td_cov_list[a], z_td[a]) for a in range(P)]
+    if Lg is not None:
+        G0 = z_gw @ Lg.T                     # [P, npts]: row a = Lg @ z_gw[a]
+        G = M @ G0
+        for a in range(P):
+            out[a] = out[a] + lerp_sorted(grid["ut"], G[a], np.asarray(toa_s_list[a], dtype=float))
+    if det is not None:
+        out = [o + d for o, d in zip(out, det)]
+    return out

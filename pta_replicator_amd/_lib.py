@@ -50,6 +50,16 @@ class EngineTables(ctypes.Structure):
     ]
 
 
+class TdPlan(ctypes.Structure):
+    """pta_td_plan (include/pta_replicator_amd.h)."""
+    _fields_ = [
+        ("Lbase", _P), ("blk_pos", _P), ("blk_ld", _P), ("blk_n", _P), ("blk_off", _P), ("item_blk", _P), ("item_n0", _P),
+        ("n_blocks", c_int32), ("n_items", c_int32), ("rows_per_real", c_int32), ("stream_kind", c_uint32),
+        ("rng_fast", c_int32), ("gw_npts", c_int32),
+        ("gw_G", _P), ("gw_jlo", _P), ("gw_w", _P), ("det", _P),
+    ]
+
+
 _SIGNATURES = {
     "pta_abi_version": (c_int, []),
     "pta_last_error": (c_char_p, []),
@@ -66,6 +76,7 @@ _SIGNATURES = {
     "pta_orf_basis": (c_int, [_P, c_int, c_int, _P, _P]),
     "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_potrf_batched": (c_int, [_P, c_int, c_int, _P, _P]),
+    "pta_potrf_batched_ex": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P]),
     "pta_set_gemm_algo": (c_int, [c_int]),
     "pta_gwb_twiddle": (c_int, [_P, c_int, c_int, c_int, c_double, _P, c_int64, _P]),
     "pta_gwb_idft": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
@@ -91,6 +102,7 @@ _SIGNATURES = {
     "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_td_trmm_rng": (c_int, [POINTER(TdPlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_double, _P, c_int64, c_int64, _P, c_int64, c_double, _P, c_int64,
                           c_int, c_int, c_int64, c_int64, c_int64, c_int, _P]),
     "pta_microbench": (c_int, [c_int, c_int64, c_int, POINTER(c_double)]),
@@ -99,6 +111,8 @@ _SIGNATURES = {
 
 ENGINE_TILE = 256   # PTA_ENGINE_TILE
 ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
+TD_STRIP = 256      # PTA_TD_STRIP
+POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION = 1, 2, 4
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -81,9 +81,9 @@ extern "C" int pta_orf_combine(const double *basis, const double *clm, int nbasi
 // and column j itself is scaled by r.  The owners of column j publish it (unscaled) through a double-buffered LDS vector:
 // ONE barrier per step, no serial section.  The tile leaves as the MFMA panel solve wants it (L below, X^T above; X's
 // diagonal 1 / L[j][j] is recomputed by the consumer).
-__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, int k0, int nb, int32_t *__restrict__ info) {
+__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n, int64_t sA, int k0, int nb, int32_t *__restrict__ info) {
   __shared__ double colbuf[2][CH_NB];
-  double *M = A + (int64_t)blockIdx.x * n * n + (int64_t)k0 * n + k0;
+  double *M = A + (int64_t)blockIdx.x * sA + (int64_t)k0 * n + k0;  // n = row pitch (lda)
   const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
   double v[4][4];
 #pragma unroll
@@ -143,13 +143,13 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int n, in
     }
 }
 
-__global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int k0, int nb) {
+__global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int nrow, int64_t n, int64_t sA, int k0, int nb) {
   __shared__ double L[CH_NB][CH_LD];
   __shared__ double X[CH_NB][CH_LD];
-  double *M = A + (int64_t)blockIdx.y * n * n;
+  double *M = A + (int64_t)blockIdx.y * sA;  // n = row pitch (lda), nrow = order of the matrix
   const int t = threadIdx.x;
   const int r0 = k0 + nb + blockIdx.x * CH_NB;
-  const int rows = min(CH_NB, n - r0);
+  const int rows = min(CH_NB, nrow - r0);
   for (int i = t >> 6; i < nb; i += 4)
     for (int c = t & 63; c < nb; c += 64) L[i][c] = M[(int64_t)(k0 + i) * n + (k0 + c)];
   for (int i = t >> 6; i < rows; i += 4)
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int n, int
 // Panel solve on the matrix cores: X <- X L11^{-T} = X . Linv^T, 64 rows per workgroup, K = 64.
 // Both operands sit row-major ("m-major") in LDS with an odd pitch, so the 16-lane fragment reads (one row each)
 // fall on distinct banks and the tile loads need no transposition.
-__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n, int k0, int nb) {
+__global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int nrow, int64_t n, int64_t sA, int k0, int nb) {
   __shared__ double Li[CH_NB][CH_LD];  // Li[c][t] = (L11^{-1})[c][t], zero for t > c
   __shared__ double X[CH_NB][CH_LD];
-  double *M = A + (int64_t)blockIdx.y * n * n;
+  double *M = A + (int64_t)blockIdx.y * sA;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int r0 = k0 + nb + blockIdx.x * CH_NB;
-  const int rows = min(CH_NB, n - r0);
+  const int rows = min(CH_NB, nrow - r0);
   for (int i = t >> 6; i < CH_NB; i += 4)
     for (int c = t & 63; c < CH_NB; c += 64) {
       // tile element (i, c) of the factored diagonal block, read along its row (coalesced): above the diagonal it is
@@ -224,10 +224,10 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
       }
 }
 
-__global__ void k_zero_upper(double *__restrict__ A, int n) {
+__global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t sA) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
-  if (c < n && c > r) A[(int64_t)blockIdx.z * n * n + (int64_t)r * n + c] = 0.0;
+  if (c < n && c > r) A[(int64_t)blockIdx.z * sA + (int64_t)r * lda + c] = 0.0;
 }
 
 static int g_gemm_algo = 1;
@@ -237,47 +237,129 @@ extern "C" int pta_set_gemm_algo(int algo) {
 }
 int pta_get_gemm_algo() { return g_gemm_algo; }
 
-extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream) {
+// Side stream + events of the look-ahead schedule below, created on first use for the calling thread's current device.
+struct pta_potrf_ctx {
+  int dev = -1;
+  hipStream_t panel = nullptr, bulk = nullptr;
+  hipEvent_t ev_in = nullptr, ev_f = nullptr, ev_b = nullptr, ev_out_p = nullptr, ev_out_b = nullptr;
+};
+static thread_local pta_potrf_ctx g_potrf_ctx;
+
+static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
+  int dev = 0;
+  PTA_HIP(hipGetDevice(&dev));
+  pta_potrf_ctx &c = g_potrf_ctx;
+  if (c.dev != dev) {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    PTA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PTA_HIP(hipStreamCreateWithPriority(&c.panel, hipStreamNonBlocking, hi));
+    PTA_HIP(hipStreamCreateWithPriority(&c.bulk, hipStreamNonBlocking, lo));
+    hipEvent_t *evs[5] = {&c.ev_in, &c.ev_f, &c.ev_b, &c.ev_out_p, &c.ev_out_b};
+    for (hipEvent_t *e : evs) PTA_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    c.dev = dev;
+  }
+  *out = &c;
+  return PTA_OK;
+}
+
+// Two-level right-looking blocking with look-ahead.  Outer panels are 256 columns wide; inside a panel, 64-wide steps
+// (diagonal block in registers -> MFMA panel solve -> update of the panel's remaining columns only).  The trailing update of
+// outer panel p is split in two:
+//   N(p): the next panel's 256 columns, on the (high-priority) panel stream, straight after the panel factorisation F(p);
+//   B(p): everything right of them (K = 256, 128 x 128 MFMA tiles over the lower-triangular tiles), on the bulk stream.
+// F(p+1) needs N(p) and B(<= p-1) only, so it runs WHILE B(p) keeps the matrix cores busy: the panel steps are short, serial
+// and memory bound (potf2 on one workgroup per matrix; the panel solve reads and writes the panel once), the bulk update is
+// MFMA bound - the two complement each other.  Hazards: N(p+1) and B(p) both accumulate into panel p+2's columns, so N(p+1)
+// waits for B(p); B(p+1) follows B(p) in stream order and waits for F(p+1).
+extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,
+                                    void *stream) {
   PTA_REQUIRE(A && info, PTA_E_ARG, "pta_potrf_batched: NULL argument");
   PTA_REQUIRE(n > 0 && n <= 65535 && B > 0 && B <= 65535, PTA_E_ARG, "pta_potrf_batched: n=%d B=%d", n, B);
+  PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
+              (long long)lda, (long long)strideA);
   hipStream_t s = pta_stream(stream);
-  PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
-  const int64_t nn = (int64_t)n * n;
-  // Two-level right-looking blocking.  A 64-wide panel step updates only the rest of its 256-wide outer panel;
-  // the bulk of the trailing matrix is updated once per outer panel with K = 256, which quarters the read+write
-  // traffic of the C tiles (at K = 64 the update is HBM-bound: 8 flop per byte of C).
   const int NBO = 4 * CH_NB;
+  const bool look = !(flags & PTA_POTRF_NO_LOOKAHEAD) && g_gemm_algo && n > 2 * NBO;
+  pta_potrf_ctx *cx = nullptr;
+  hipStream_t sp = s, sb = s;  // panel / bulk streams (the caller's stream when there is nothing to overlap)
+  PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
+  if (look) {
+    int rc = pta_potrf_ctx_get(&cx);
+    if (rc != PTA_OK) return rc;
+    sp = cx->panel;
+    sb = cx->bulk;
+    PTA_HIP(hipEventRecord(cx->ev_in, s));
+    PTA_HIP(hipStreamWaitEvent(sp, cx->ev_in, 0));
+    PTA_HIP(hipStreamWaitEvent(sb, cx->ev_in, 0));
+  }
+  bool bulk_pending = false;
   for (int k0 = 0; k0 < n; k0 += NBO) {
     const int nbo = (n - k0 < NBO) ? (n - k0) : NBO;
     const int pend = k0 + nbo;  // one past the outer panel's last column
+    // ---- F(p): factor the outer panel, 64 columns at a time -------------------------------------------------------
     for (int j0 = k0; j0 < pend; j0 += CH_NB) {
       const int nb = (pend - j0 < CH_NB) ? (pend - j0) : CH_NB;
-      hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, s, A, n, j0, nb, info);
+      hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, sp, A, lda, strideA, j0, nb, info);
       PTA_LAUNCH_CHECK();
       const int rows = n - j0 - nb;
       if (rows <= 0) continue;
-      if (g_gemm_algo)
-        hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
+      if (g_gemm_algo && !(flags & PTA_POTRF_SUBSTITUTION))
+        hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, strideA, j0, nb);
       else
-        hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, s, A, n, j0, nb);
+        hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, strideA, j0, nb);
       PTA_LAUNCH_CHECK();
       const int pcols = pend - (j0 + nb);  // columns of the outer panel still to be factored
       if (pcols > 0) {
-        const double *L21 = A + (int64_t)(j0 + nb) * n + j0;
-        double *A22 = A + (int64_t)(j0 + nb) * n + (j0 + nb);
-        int rc = pta_dgemm_launch(1, rows, pcols, nb, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
+        const double *L21 = A + (int64_t)(j0 + nb) * lda + j0;
+        double *A22 = A + (int64_t)(j0 + nb) * lda + (j0 + nb);
+        int rc = pta_dgemm_launch(1, rows, pcols, nb, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, sp);
         if (rc != PTA_OK) return rc;
       }
     }
     const int rows = n - pend;
-    if (rows > 0) {
-      const double *L21 = A + (int64_t)pend * n + k0;
-      double *A22 = A + (int64_t)pend * n + pend;
-      int rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, n, 1, L21, n, 1.0, A22, n, 1, B, nn, nn, nn, g_gemm_algo, s);
+    if (rows <= 0) break;
+    const double *L21 = A + (int64_t)pend * lda + k0;
+    double *A22 = A + (int64_t)pend * lda + pend;
+    if (!look) {
+      int rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, s);
+      if (rc != PTA_OK) return rc;
+      continue;
+    }
+    // ---- B(p) on the bulk stream: columns right of the next panel ---------------------------------------------------
+    const int ncols = rows < NBO ? rows : NBO;  // the next panel's columns
+    PTA_HIP(hipEventRecord(cx->ev_f, sp));
+    if (rows > ncols) {
+      PTA_HIP(hipStreamWaitEvent(sb, cx->ev_f, 0));
+      const double *L21b = L21 + (int64_t)ncols * lda;
+      double *A22b = A22 + (int64_t)ncols * lda + ncols;
+      int rc = pta_dgemm_launch(1, rows - ncols, rows - ncols, nbo, -1.0, L21b, lda, 1, L21b, lda, 1.0, A22b, lda, 1, B, strideA, strideA, strideA,
+                                g_gemm_algo, sb);
       if (rc != PTA_OK) return rc;
     }
+    // ---- N(p) on the panel stream: the next panel's columns, after the previous bulk update that also touched them ----
+    if (bulk_pending) PTA_HIP(hipStreamWaitEvent(sp, cx->ev_b, 0));
+    {
+      int rc = pta_dgemm_launch(1, rows, ncols, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, sp);
+      if (rc != PTA_OK) return rc;
+    }
+    if (rows > ncols) {
+      PTA_HIP(hipEventRecord(cx->ev_b, sb));
+      bulk_pending = true;
+    }
   }
-  hipLaunchKernelGGL(k_zero_upper, dim3(pta_cdiv(n, 256), n, B), dim3(256), 0, s, A, n);
-  PTA_LAUNCH_CHECK();
+  if (look) {  // join: the caller's stream continues after both
+    PTA_HIP(hipEventRecord(cx->ev_out_p, sp));
+    PTA_HIP(hipEventRecord(cx->ev_out_b, sb));
+    PTA_HIP(hipStreamWaitEvent(s, cx->ev_out_p, 0));
+    PTA_HIP(hipStreamWaitEvent(s, cx->ev_out_b, 0));
+  }
+  if (flags & PTA_POTRF_ZERO_UPPER) {
+    hipLaunchKernelGGL(k_zero_upper, dim3(pta_cdiv(n, 256), n, B), dim3(256), 0, s, A, n, lda, strideA);
+    PTA_LAUNCH_CHECK();
+  }
   return PTA_OK;
+}
+
+extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream) {
+  return pta_potrf_batched_ex(A, n, n, (int64_t)n * n, B, info, PTA_POTRF_ZERO_UPPER, stream);
 }

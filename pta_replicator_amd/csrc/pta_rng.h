@@ -28,7 +28,8 @@
 #define PTA_STREAM_RN 2u    // + pulsar index: pair p -> coefficients (2p, 2p+1)                 (red_noise.py:127)
 #define PTA_STREAM_WN 3u    // + pulsar index: pair p = TOA i -> (z1[i], z2[i])                  (white_noise.py:105-109)
 #define PTA_STREAM_ECORR 4u // + pulsar index: pair p = epoch e>>1, branch e&1                   (white_noise.py:182)
-#define PTA_STREAM_TD 5u    // + pulsar index: TD-mode z[i], pair p = i>>1, branch i&1
+#define PTA_STREAM_TD 5u    // + pulsar index: TD-mode z[i] of the pulsar's N_a x N_a factor, pair p = i>>1, branch i&1
+#define PTA_STREAM_TDGW 6u  // + pulsar index: TD-mode z[j] of the npts x npts GWB grid factor, pair p = j>>1, branch j&1
 
 PTA_HD uint32_t pta_stream_id(uint32_t kind, uint32_t pulsar) { return (kind << 24) | (pulsar & 0xFFFFFFu); }
 

@@ -5,6 +5,7 @@
 // (red_noise.py:98-101,126-128; white_noise.py:105-109,182).
 #include "pta_common.h"
 #include "pta_mfma.h"
+#include "pta_rng.h"
 
 #define TBM 64
 #define TBK 16
@@ -77,9 +78,9 @@ __global__ __launch_bounds__(256) void k_td_cov(const double *__restrict__ Ft, i
 
 extern "C" int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const double *phi, const double *sigma2,
                                    const int32_t *epoch_of, const double *ecorr2, double *C, int64_t ldc, void *stream) {
-  PTA_REQUIRE(Ft && phi && sigma2 && C, PTA_E_ARG, "pta_td_cov_assemble: NULL argument");
+  PTA_REQUIRE(sigma2 && C && (K == 0 || (Ft && phi)), PTA_E_ARG, "pta_td_cov_assemble: NULL argument");
   PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble: ecorr2 missing");
-  PTA_REQUIRE(N > 0 && K > 0 && ldf >= N && ldc >= N && pta_cdiv(N, TBM) <= 65535u, PTA_E_ARG, "pta_td_cov_assemble: N=%d K=%d", N, K);
+  PTA_REQUIRE(N > 0 && K >= 0 && (K == 0 || ldf >= N) && ldc >= N && pta_cdiv(N, TBM) <= 65535u, PTA_E_ARG, "pta_td_cov_assemble: N=%d K=%d", N, K);
   unsigned nt = pta_cdiv(N, TBM);
   hipLaunchKernelGGL(k_td_cov, dim3(nt * (nt + 1) / 2), dim3(256), 0, pta_stream(stream), Ft, ldf, N, K, phi, sigma2, epoch_of, ecorr2, C,
                      ldc);
@@ -96,4 +97,164 @@ extern "C" int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z,
   PTA_REQUIRE(N > 0 && R > 0 && ldl >= N && ld_z >= N && ld_out >= N, PTA_E_ARG, "pta_td_trmm: N=%d R=%d", N, R);
   return pta_dgemm_launch(1, R, N, N, 1.0, z, ld_z, 1, L, ldl, accumulate ? 1.0 : 0.0, out, ld_out, 0, 1, 0, 0, 0, pta_get_gemm_algo(),
                           pta_stream(stream));
+}
+
+// ---- L . z with the deviates drawn in registers -------------------------------------------------------------------
+// The draw of the dense path: out[m, i] = sum_{j <= i} L[i, j] z[m, j], i.e. Z . L^T with Z never stored anywhere - lane l of
+// a wave holds the MFMA A operand Z[m = l & 15][k = l >> 4] and simply GENERATES it (Philox + Box-Muller, pta_rng.h), the way
+// k_gwb_idft_sym_rng does for the GWB draws.  One workgroup = a strip of TDS_N = 256 rows of one factor (= 256 output
+// columns) x TDS_M = 64 rows of Z (16 per wave); the strip of L streams once through LDS in K slabs of 16, double buffered,
+// and is shared by the four waves.  Per slab a wave issues 64 MFMAs (16 column tiles x 4 K steps) against two Box-Muller
+// pairs per lane (the four K steps use k = 4 q + s, q = l >> 4, so a lane's four deviates of a slab are exactly the pairs
+// (k0 >> 1) + 2 q and + 1): ~300 VALU instructions beside 64 x 64 matrix-pipe cycles.  Every deviate is regenerated by each
+// strip that needs it (N / 512 times on average) - VALU work the matrix pipe hides - instead of being written to and re-read
+// from an [R, N] buffer.
+// LDS pitch 260 doubles: the two half-wave lane groups of a ds_read_b64 read rows 4 apart -> 4 * 260 * 2 = 32 (mod 64) dwords,
+// i.e. disjoint bank halves; a 16-lane store group writes 16 consecutive doubles = all 32 banks once.
+#define TDS_N PTA_TD_STRIP
+#define TDS_M 64
+#define TDS_K 16
+#define TDS_LD 260
+#define TDS_NT (TDS_N / 16)
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t seed, uint64_t r0, int M, double *__restrict__ out,
+                                                        int64_t ld_out) {
+  constexpr int fast = FAST ? 1 : 0;
+  __shared__ double Bs[2][TDS_K][TDS_LD];
+  // work item order: items are sorted by decreasing K extent (host); consecutive workgroups go to the 8 XCDs round-robin, so
+  // XCD x takes items x, x + 8, ... (each XCD gets the same mix of long and short strips) and walks the Z-row groups of one
+  // item back to back: the strip of L is fetched into ONE L2 and re-read there by the other row groups.
+  const int nmg = (M + TDS_M - 1) / TDS_M;
+  const int lin = blockIdx.x;
+  const int seq = lin >> 3;
+  const int item = (seq / nmg) * 8 + (lin & 7);
+  if (item >= pl.n_items) return;
+  const int mg = seq % nmg;
+  const int blk = pl.item_blk[item];
+  const int n0 = pl.item_n0[item];
+  const int n = pl.blk_n[blk];
+  const int64_t ldl = pl.blk_ld[blk];
+  const double *__restrict__ L = pl.Lbase + pl.blk_pos[blk];
+  const int t = threadIdx.x, l = t & 63, wv = t >> 6;
+  const int c = l & 15, q = l >> 4;
+  const int kend = min(n, n0 + TDS_N);  // L[i, j] = 0 for j > i: columns beyond the strip's last row contribute nothing
+  const int nslab = (kend + TDS_K - 1) / TDS_K;
+
+  // the Z row of this lane's A operand: m = realisation (rows_per_real == 1) or (realisation, pulsar) of the grid factor
+  const int m_a = mg * TDS_M + wv * 16 + c;
+  const int rpr = pl.rows_per_real;
+  const uint64_t real_a = r0 + (uint64_t)(m_a / rpr);
+  const uint32_t strm_a = pta_stream_id(pl.stream_kind, (uint32_t)(rpr == 1 ? blk : (m_a % rpr)));
+
+  pta_f64x4 acc[TDS_NT];
+#pragma unroll
+  for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+
+  // global -> register fetch of one slab: rows wv * 64 + c + 16 g (g < 4), k pairs q + 4 h (h < 2), as double2
+  double2 rg[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = n0 + wv * 64 + c + 16 * g;
+        const int k = k0 + 2 * (q + 4 * h);
+        double2 v = make_double2(0.0, 0.0);
+        if (row < n) {
+          const double *p = L + (int64_t)row * ldl + k;
+          if (k + 1 <= row)
+            v = *reinterpret_cast<const double2 *>(p);  // both columns on or below the diagonal
+          else if (k == row)
+            v.x = *p;                                    // the diagonal element; the one right of it counts as zero
+        }
+        rg[2 * g + h] = v;
+      }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = wv * 64 + c + 16 * g, kk = 2 * (q + 4 * h);
+        Bs[buf][kk][row] = rg[2 * g + h].x;
+        Bs[buf][kk + 1][row] = rg[2 * g + h].y;
+      }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int cur = s & 1;
+    const int k0 = s * TDS_K;
+    if (s + 1 < nslab) fetch(k0 + TDS_K);
+    double z[4];
+    const uint32_t p0 = (uint32_t)((k0 >> 1) + 2 * q);
+    pta_normal_pair(seed, real_a, strm_a, p0, z[0], z[1], fast);
+    pta_normal_pair(seed, real_a, strm_a, p0 + 1u, z[2], z[3], fast);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      double b[TDS_NT];
+#pragma unroll
+      for (int j = 0; j < TDS_NT; ++j) b[j] = Bs[cur][4 * q + st][16 * j + c];
+#pragma unroll
+      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[st], b[j], acc[j]);
+    }
+    if (s + 1 < nslab) stash(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds rows (Z rows) q + 4 reg of the wave's 16 and column 16 j + c of the strip
+  const bool epi = pl.gw_G != nullptr;
+  const int ocol0 = pl.blk_off[blk];
+#pragma unroll
+  for (int j = 0; j < TDS_NT; ++j) {
+    const int i = n0 + 16 * j + c;
+    if (i >= n) continue;
+    const int64_t oc = (int64_t)ocol0 + i;
+    double add = 0.0, wgt = 0.0;
+    int jl = 0;
+    if (pl.det) add = pl.det[oc];
+    if (epi) {
+      jl = pl.gw_jlo[oc];
+      wgt = pl.gw_w[oc];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int m = mg * TDS_M + wv * 16 + q + 4 * reg;
+      if (m >= M) continue;
+      double v = acc[j][reg];
+      if (epi) {  // + GWB: linear interpolation of the mixed grid series of (realisation m, pulsar blk) (red_noise.py:286-287)
+        const double *gp = pl.gw_G + ((int64_t)m * pl.n_blocks + blk) * pl.gw_npts;
+        const double y0 = gp[jl];
+        v = v + ((gp[jl + 1] - y0) * wgt + y0);
+      }
+      out[(int64_t)m * ld_out + oc] = v + add;
+    }
+  }
+}
+
+extern "C" int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out,
+                               void *stream) {
+  PTA_REQUIRE(plan_host && out, PTA_E_ARG, "pta_td_trmm_rng: NULL argument");
+  const pta_td_plan &p = *plan_host;
+  PTA_REQUIRE(p.Lbase && p.blk_pos && p.blk_ld && p.blk_n && p.blk_off && p.item_blk && p.item_n0, PTA_E_ARG,
+              "pta_td_trmm_rng: plan arrays missing");
+  PTA_REQUIRE(p.n_blocks > 0 && p.n_items > 0 && p.rows_per_real > 0 && M > 0, PTA_E_ARG, "pta_td_trmm_rng: n_blocks=%d n_items=%d M=%d",
+              p.n_blocks, p.n_items, M);
+  PTA_REQUIRE(p.rows_per_real == 1 || p.n_blocks == 1, PTA_E_ARG, "pta_td_trmm_rng: rows_per_real > 1 needs a single factor block");
+  PTA_REQUIRE(p.rows_per_real == 1 || M % p.rows_per_real == 0, PTA_E_ARG, "pta_td_trmm_rng: M=%d is not a multiple of rows_per_real=%d",
+              M, p.rows_per_real);
+  PTA_REQUIRE(!p.gw_G || (p.rows_per_real == 1 && p.gw_jlo && p.gw_w && p.gw_npts >= 2), PTA_E_ARG,
+              "pta_td_trmm_rng: GWB epilogue needs rows_per_real == 1, gw_jlo, gw_w, gw_npts >= 2");
+  PTA_REQUIRE(((uintptr_t)p.Lbase % 16) == 0, PTA_E_ARG, "pta_td_trmm_rng: Lbase must be 16-byte aligned");
+  const int64_t nmg = pta_cdiv(M, TDS_M);
+  const int64_t nwg = (int64_t)((p.n_items + 7) / 8) * 8 * nmg;
+  PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_td_trmm_rng: %lld workgroups exceed one launch", (long long)nwg);
+  if (p.rng_fast)
+    hipLaunchKernelGGL(k_td_trmm_rng<true>, dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
+  else
+    hipLaunchKernelGGL(k_td_trmm_rng<false>, dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
 }

@@ -27,6 +27,10 @@ def i32(x, device=None):
     return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.int32)), device=device or require_gpu())
 
 
+def i64(x, device=None):
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.int64)), device=device or require_gpu())
+
+
 def empty(shape, dtype=torch.float64, device=None):
     return torch.empty(shape, dtype=dtype, device=device or require_gpu())
 

@@ -30,15 +30,16 @@ from . import red_noise as rn
 from . import white_noise as wn
 from ._position import ra_dec
 from .constants import DAY_IN_SEC, YEAR_IN_SEC
+from .engine_td import TimeDomainMixin
 
-STREAM_GWB, STREAM_RN, STREAM_WN, STREAM_ECORR, STREAM_TD = 1, 2, 3, 4, 5
+STREAM_GWB, STREAM_RN, STREAM_WN, STREAM_ECORR, STREAM_TD, STREAM_TDGW = 1, 2, 3, 4, 5, 6
 
 
 def stream_id(kind, pulsar):
     return ((kind << 24) | (pulsar & 0xFFFFFF)) & 0xFFFFFFFF
 
 
-class ReplicaEngine:
+class ReplicaEngine(TimeDomainMixin):
     def __init__(self, psrs, seed=0):
         self.psrs = list(psrs)
         self.P = len(self.psrs)
@@ -111,6 +112,7 @@ class ReplicaEngine:
     def prepare(self):
         dev = dv.require_gpu()
         self._ws = None  # tables of a previous prepare() point at replaced buffers
+        self._td_prepared = False  # and so do the dense factors of TD mode
         s = dv.stream_ptr()
         P, N = self.P, self.n_toa
         self.d_psr_of = dv.i32(np.repeat(np.arange(P), self.counts))

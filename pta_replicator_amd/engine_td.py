@@ -1,0 +1,221 @@
+"""TD ("time-domain") mode of the ReplicaEngine: the dense path BASELINE.json's north_star names.
+
+    per-pulsar covariance assembly  ->  batched blocked Cholesky (fp64 MFMA trailing update)  ->  L . z against Gaussian
+    deviates drawn on chip  ->  + GWB  ->  residuals
+
+The reference never forms an N_toa x N_toa object; what is factored here is the covariance its synthesis
+implies:
+
+    C_a = F diag(phi) F^T                                   red_noise.py:98-101,126-128 (rank 2 * components)
+        + diag((efac sigma)^2 + (efac equad | equad)^2)     white_noise.py:105-109
+        + sum_e ecorr_e^2 1_e 1_e^T                         white_noise.py:182
+    GWB on the npts-sample grid: Sigma_g = T^T T, T the twiddle matrix of the pruned inverse DFT (sqrt(C(f)) folded in,
+        red_noise.py:265-285) - the Toeplitz matrix 4/(dt^2 n^2) sum_k C_k cos(2 pi k (p - q) / n) of App. A.1 - times the
+        ORF between pulsars (red_noise.py:224-235), then the same linear interpolation onto the TOAs (:286-287).
+
+``prepare_td()`` assembles and factors once (one L_a per pulsar, one L_g for the grid); ``generate_td(R)`` then costs one
+triangular product per pulsar per realisation, with every deviate generated in registers as the MFMA A operand
+(``pta_td_trmm_rng``: stream (TD, a) for the N_a deviates of pulsar a, (TDGW, a) for its npts grid deviates).  A TD realisation
+has the same distribution as a throughput-mode one but is not draw-for-draw comparable with the reference (different
+deviates); its CPU oracle is ``oracle/pta_oracle.py: td_*`` on the dumped deviates (``dump_draws_td``).
+
+Conditioning.  Sigma_g spans the spectrum's full dynamic range over the grid (condition number ~3e14 for gamma = 13/3), so
+two correct Cholesky factorisations agree only to ~cond * eps in the factor; what is pinned for it is the backward error
+|| L L^T - Sigma || / || Sigma || (tests) - the realisations are exact draws of N(0, L L^T).  If the device factorisation
+meets a non-positive pivot, a relative diagonal jitter (1e-14 of the mean diagonal, x10 per retry) is added and recorded in
+``gw_td_jitter``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, device as dv
+
+STREAM_TD, STREAM_TDGW = 5, 6
+
+
+def _strips(counts, strip=_lib.TD_STRIP):
+    """work items (block, first row) of the triangular product, longest K extent first."""
+    items = [(min(int(n), n0 + strip), b, n0) for b, n in enumerate(counts) for n0 in range(0, int(n), strip)]
+    items.sort(key=lambda x: -x[0])
+    return np.array([x[1] for x in items], dtype=np.int32), np.array([x[2] for x in items], dtype=np.int32)
+
+
+class TimeDomainMixin:
+    # ---------------------------------------------------------------- prepare -------------------
+    def prepare_td(self, lookahead=True):
+        """assemble and factor the dense covariances (once per array and noise model)."""
+        if not self._prepared:
+            self.prepare()
+        if self._wn is None:
+            raise ValueError("TD mode needs measurement noise (set_white_noise): without it the dense covariance is singular")
+        P, N = self.P, self.n_toa
+        s = dv.stream_ptr()
+        pl = self.plan
+        counts = [int(c) for c in self.counts]
+        ld = [(n + 1) // 2 * 2 for n in counts]           # even leading dimensions: the product kernel loads double2
+        pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(counts, ld)])]).astype(np.int64)
+        self.td_ld, self.td_pos = ld, pos
+        self.d_Ltd = dv.empty((int(pos[-1]),))
+        sigma2 = self.d_wn_a ** 2 + self.d_wn_b ** 2      # (efac sigma)^2 + (efac equad | equad)^2
+        self._td_sigma2 = sigma2
+        K = pl.rn_k
+        phi = (self.d_amp ** 2).contiguous() if K else None
+        ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
+        for a in range(P):
+            o = int(self.off[a])
+            _lib.call("pta_td_cov_assemble",
+                      ctypes.c_void_p(self.d_Ft.data_ptr() + 8 * o) if K else None, N, counts[a], K,
+                      ctypes.c_void_p(phi.data_ptr() + 8 * a * K) if K else None,
+                      ctypes.c_void_p(sigma2.data_ptr() + 8 * o),
+                      ctypes.c_void_p(self.d_epoch_of.data_ptr() + 4 * o) if ecorr2 is not None else None,
+                      ctypes.c_void_p(ecorr2.data_ptr() + 8 * o) if ecorr2 is not None else None,
+                      ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), ld[a], s)
+        # batched factorisation: runs of consecutive pulsars with the same TOA count share one launch sequence
+        info = dv.zeros((P,), dtype=torch.int32)
+        flags = 0 if lookahead else _lib.POTRF_NO_LOOKAHEAD
+        a = 0
+        while a < P:
+            b = a
+            while b + 1 < P and counts[b + 1] == counts[a]:
+                b += 1
+            _lib.call("pta_potrf_batched_ex", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), counts[a], ld[a],
+                      counts[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, s)
+            a = b + 1
+        bad = info.cpu().numpy()
+        if np.any(bad != 0):
+            a = int(np.nonzero(bad)[0][0])
+            raise np.linalg.LinAlgError(f"TD covariance of {self.names[a]} is not positive definite (leading minor {int(bad[a])})")
+        blk, n0 = _strips(counts)
+        self._td_keep = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1]), dv.i32(blk), dv.i32(n0)]
+        tp = _lib.TdPlan()
+        tp.Lbase = self.d_Ltd.data_ptr()
+        tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in self._td_keep]
+        tp.n_blocks, tp.n_items, tp.rows_per_real, tp.stream_kind, tp.rng_fast = P, len(blk), 1, STREAM_TD, 0
+        tp.det = pl.det
+        self.td_plan = tp
+
+        # ---- GWB: factor of the grid covariance Sigma_g = T^T T (realisation independent, shared by all pulsars)
+        self.tdgw_plan = None
+        if pl.gw_npts:
+            npts, Nf = pl.gw_npts, self.grid["Nf"]
+            ldg = (npts + 1) // 2 * 2
+            Sg = dv.zeros((npts, ldg))
+            _lib.call("pta_dgemm", 0, npts, npts, 2 * (Nf - 2), ctypes.c_double(1.0), dv.ptr(self.d_T), 1, self.ldt, dv.ptr(self.d_T),
+                      self.ldt, ctypes.c_double(0.0), dv.ptr(Sg), ldg, 1, 1, 0, 0, 0, 1, s)
+            self.Sg_td = Sg
+            ginfo = dv.zeros((1,), dtype=torch.int32)
+            mean_diag = float(torch.diagonal(Sg[:, :npts]).mean().item())
+            eps, self.gw_td_jitter = 0.0, 0.0
+            while True:
+                Lg = Sg.clone()
+                if eps:
+                    torch.diagonal(Lg[:, :npts]).add_(eps * mean_diag)
+                _lib.call("pta_potrf_batched_ex", dv.ptr(Lg), npts, ldg, npts * ldg, 1, dv.ptr(ginfo), _lib.POTRF_SUBSTITUTION, s)
+                if int(ginfo.item()) == 0:
+                    break
+                eps = 1e-14 if eps == 0.0 else eps * 10.0
+                if eps > 1e-8:
+                    raise np.linalg.LinAlgError("GWB grid covariance is not positive definite even with 1e-8 relative jitter")
+            self.gw_td_jitter = eps
+            self.d_Lg, self.td_ldg = Lg, ldg
+            gblk, gn0 = _strips([npts])
+            self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0)]
+            gp = _lib.TdPlan()
+            gp.Lbase = Lg.data_ptr()
+            gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0 = [x.data_ptr() for x in self._tdgw_keep]
+            gp.n_blocks, gp.n_items, gp.rows_per_real, gp.stream_kind, gp.rng_fast = 1, len(gblk), P, STREAM_TDGW, 0
+            self.tdgw_plan = gp
+            tp.gw_npts, tp.gw_jlo, tp.gw_w = npts, self.d_jlo.data_ptr(), self.d_gw_w.data_ptr()
+        self._td_ws = None
+        self._td_prepared = True
+        return self
+
+    # ---------------------------------------------------------------- generate ------------------
+    def generate_td(self, R, r0=0, out=None, chunk=4096):
+        """out[R, n_toa] (device, seconds): realisations r0 .. r0+R-1 of the dense path, deviates drawn on chip."""
+        if not getattr(self, "_td_prepared", False) or not self._prepared:
+            self.prepare_td()
+        if out is None:
+            out = dv.empty((R, self.n_toa))
+        s = dv.stream_ptr()
+        P, npts = self.P, self.plan.gw_npts
+        tp = self.td_plan
+        chunk = int(min(chunk, R))
+        if npts:
+            ws = self._td_ws
+            if ws is None or ws[0].shape[0] < chunk:
+                ws = self._td_ws = (dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts)))
+            tp.gw_G = ws[1].data_ptr()
+        for lo in range(0, R, chunk):
+            n = min(chunk, R - lo)
+            if npts:
+                _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(ws[0]), npts, s)
+                _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), s)
+            _lib.call("pta_td_trmm_rng", ctypes.byref(tp), self.seed, r0 + lo, n, ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)),
+                      out.stride(0), s)
+        return out
+
+    # ---------------------------------------------------------------- draws / replay ------------
+    def dump_draws_td(self, r):
+        """the deviates realisation r uses in generate_td(): {'td': [z_a[N_a]], 'gwb': z[P, npts] (if a GWB is set)}."""
+        if not getattr(self, "_td_prepared", False):
+            self.prepare_td()
+        from .engine import stream_id
+        s = dv.stream_ptr()
+        d = {"td": []}
+        for a in range(self.P):
+            n = int(self.counts[a])
+            npair = (n + 1) // 2
+            buf = dv.empty((2 * npair,))
+            _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_TD, a), npair, 1, dv.ptr(buf), None, 2 * npair, s)
+            d["td"].append(buf.cpu().numpy()[:n])
+        if self.plan.gw_npts:
+            npts = self.plan.gw_npts
+            npair = (npts + 1) // 2
+            buf = dv.empty((self.P, 2 * npair))
+            for a in range(self.P):
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_TDGW, a), npair, 1,
+                          ctypes.c_void_p(buf.data_ptr() + 16 * npair * a), None, 2 * npair, s)
+            d["gwb"] = buf.cpu().numpy()[:, :npts]
+        return d
+
+    def td_factor(self, a):
+        """lower Cholesky factor of pulsar a's covariance as a [N_a, N_a] device tensor (copy, upper triangle zeroed)."""
+        n, ld = int(self.counts[a]), self.td_ld[a]
+        v = self.d_Ltd[int(self.td_pos[a]):int(self.td_pos[a]) + n * ld].view(n, ld)[:, :n]
+        return torch.tril(v).contiguous()
+
+    def gw_grid_factor(self):
+        """lower Cholesky factor of the GWB grid covariance as a [npts, npts] device tensor (copy, upper triangle zeroed)."""
+        npts = self.plan.gw_npts
+        return torch.tril(self.d_Lg[:, :npts]).contiguous()
+
+    def replay_td(self, draws_list):
+        """caller-supplied deviates (shaped like dump_draws_td()) through the explicit-operand kernels - pta_td_trmm (plain
+        MFMA GEMM on a stored Z), pta_gwb_mix, pta_gwb_interp: the cross-check of the in-register-draw kernel."""
+        if not getattr(self, "_td_prepared", False):
+            self.prepare_td()
+        s = dv.stream_ptr()
+        R, P, N = len(draws_list), self.P, self.n_toa
+        out = dv.zeros((R, N))
+        for a in range(P):
+            n = int(self.counts[a])
+            L = self.td_factor(a)
+            z = dv.f64(np.stack([d["td"][a] for d in draws_list]))
+            _lib.call("pta_td_trmm", dv.ptr(L), n, n, dv.ptr(z), n, R, ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, s)
+            torch.cuda.current_stream().synchronize()
+        if self.plan.gw_npts:
+            npts = self.plan.gw_npts
+            Lg = self.gw_grid_factor()
+            zg = dv.f64(np.stack([d["gwb"] for d in draws_list]).reshape(R * P, npts))
+            G0, G = dv.empty((R * P, npts)), dv.empty((R * P, npts))
+            _lib.call("pta_td_trmm", dv.ptr(Lg), npts, npts, dv.ptr(zg), npts, R * P, dv.ptr(G0), npts, 0, s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), s)
+            _lib.call("pta_gwb_interp", dv.ptr(G), npts, P, npts, dv.ptr(self.d_ut), dv.ptr(self.d_toa_s), dv.ptr(self.d_psr_of),
+                      dv.ptr(self.d_jlo), N, R, ctypes.c_double(1.0), dv.ptr(out), N, 1, s)
+        if self.plan.det:
+            out += self.d_det
+        torch.cuda.current_stream().synchronize()
+        return out

@@ -12,9 +12,9 @@ def one():
     t = {}
     torch.cuda.synchronize(); t0 = time.perf_counter()
     add_gwb(psrs, noise["gw_log10_A"], 13. / 3., seed=16672); torch.cuda.synchronize(); t["gwb"] = time.perf_counter() - t0; t0 = time.perf_counter()
-    for ii, p in enumerate(psrs): add_measurement_noise(p, efac=noise["efac"][ii], log10_equad=noise["log10_equad"][ii], seed=10660 + ii)
+    for ii, p in enumerate(psrs): add_measurement_noise(p, efac=noise["efac"][ii], log10_equad=noise["log10_equad"][ii], flags=noise["flags"][ii], seed=10660 + ii)
     torch.cuda.synchronize(); t["wn"] = time.perf_counter() - t0; t0 = time.perf_counter()
-    for ii, p in enumerate(psrs): add_jitter(p, log10_ecorr=noise["log10_ecorr"][ii], coarsegrain=0.1, seed=17763 + ii)
+    for ii, p in enumerate(psrs): add_jitter(p, log10_ecorr=noise["log10_ecorr"][ii], flags=noise["flags"][ii], coarsegrain=0.1, seed=17763 + ii)
     torch.cuda.synchronize(); t["ecorr"] = time.perf_counter() - t0; t0 = time.perf_counter()
     for ii, p in enumerate(psrs):
         if noise["rn_log10_A"][ii] is not None: add_red_noise(p, noise["rn_log10_A"][ii], noise["rn_gamma"][ii], components=30, seed=19870 + ii)

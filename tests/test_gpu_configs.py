@@ -72,17 +72,14 @@ def test_config4_headline_array_with_cgw():
     """68 x 5000 + one continuous-wave source (the reference test's CW parameters): the deterministic term is added
     once per TOA and is identical in every realisation."""
     from pta_replicator_amd.engine import ReplicaEngine
-    from bench import headline_array
+    from bench import configure_engine, headline_array
     psrs, noise = headline_array(68, 5000)
     cw = dict(gwtheta=np.pi / 2, gwphi=2.5, mc=1e9, dist=5.0, fgw=1e-8, phase0=0.5, psi=1.5, inc=np.pi / 4, pdist=1.0,
               pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=53000 * 86400)
 
     def build(with_cw):
         e = ReplicaEngine(psrs, seed=4)
-        e.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"])
-        e.set_jitter(log10_ecorr=noise["log10_ecorr"])
-        e.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"])
-        e.set_gwb(noise["gw_log10_A"], 13. / 3.)
+        configure_engine(e, noise)
         if with_cw:
             e.add_cgw(**cw)
         return e.prepare()

@@ -1,0 +1,304 @@
+"""TD ("time-domain") mode on the GPU: dense covariance -> blocked Cholesky -> L . z with on-chip deviates (+ GWB), the path
+BASELINE.json's north_star names.  Oracle: oracle/pta_oracle.py td_* (NumPy / LAPACK) on the deviates the kernels drew.
+
+Tolerances.  1e-10 relative RMS wherever the comparison is between two evaluations of the SAME linear map (device product vs
+NumPy product with the same factor) and for the per-pulsar factors (condition number <~ 1e8).  The GWB grid covariance has a
+condition number of ~3e14: two correct float64 Cholesky factorisations of it differ by ~cond * eps, LAPACK's included (measured
+below against an 80-bit factorisation), so the device factor is pinned by its BACKWARD error (< 1e-12 and within 10x of
+LAPACK's on the same matrix) and by a forward error no worse than 20x LAPACK's.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import relrms
+from oracle import pta_oracle as po
+from oracle import philox_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from pta_replicator_amd import _lib, device as dv
+    return {"torch": torch, "lib": _lib, "dv": dv, "s": dv.stream_ptr()}
+
+
+def _plan(gpu, Ls, lds, rows_per_real, kind, keep):
+    """pta_td_plan over a list of host factors (row-major, leading dimension lds[b]); the upper triangles hold NaN."""
+    lib, dv = gpu["lib"], gpu["dv"]
+    from pta_replicator_amd.engine_td import _strips
+    ns = [L.shape[0] for L in Ls]
+    pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(ns, lds)])]).astype(np.int64)
+    buf = np.full(int(pos[-1]), np.nan)
+    for b, L in enumerate(Ls):
+        v = buf[pos[b]:pos[b] + ns[b] * lds[b]].reshape(ns[b], lds[b])
+        il = np.tril_indices(ns[b])
+        v[il] = L[il]
+    off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int32)
+    blk, n0 = _strips(ns)
+    dev = [dv.f64(buf), dv.i64(pos[:-1]), dv.i32(lds), dv.i32(ns), dv.i32(off[:-1] if rows_per_real == 1 else [0]), dv.i32(blk), dv.i32(n0)]
+    keep.extend(dev)
+    tp = lib.TdPlan()
+    tp.Lbase = dev[0].data_ptr()
+    tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in dev[1:]]
+    tp.n_blocks, tp.n_items, tp.rows_per_real, tp.stream_kind, tp.rng_fast = len(Ls), len(blk), rows_per_real, kind, 0
+    return tp, off
+
+
+def _normals(gpu, seed, r, kind, psr, n):
+    lib, dv = gpu["lib"], gpu["dv"]
+    npair = (n + 1) // 2
+    buf = dv.empty((2 * npair,))
+    lib.call("pta_rng_fill_normal", seed, r, 1, philox_ref.stream_id(kind, psr), npair, 1, dv.ptr(buf), None, 2 * npair, gpu["s"])
+    return buf.cpu().numpy()[:n]
+
+
+@pytest.mark.parametrize("sizes,R", [((1, 17, 256, 257), 5), ((300, 333, 513), 70), ((1024,), 64), ((2,), 1)])
+def test_td_trmm_rng_per_pulsar_blocks(gpu, sizes, R):
+    """out[m, off_b + i] = sum_{j <= i} L_b[i, j] z(m, b, j) with z generated in registers: ragged factor orders (strip
+    remainders, a 1 x 1 factor), odd orders with padded leading dimensions, realisation counts off the 64-row groups, NaN above
+    the diagonals (never read)."""
+    lib, dv = gpu["lib"], gpu["dv"]
+    rng = np.random.default_rng(sum(sizes) + R)
+    Ls = [np.tril(rng.standard_normal((n, n))) + 3 * np.eye(n) for n in sizes]
+    lds = [(n + 1) // 2 * 2 + (2 if b % 2 else 0) for b, n in enumerate(sizes)]
+    keep = []
+    tp, off = _plan(gpu, Ls, lds, 1, 5, keep)
+    ntot = int(off[-1])
+    out = dv.f64(np.full((R, ntot + 3), 7.0))
+    seed, r0 = 99, 1234567890123
+    lib.call("pta_td_trmm_rng", ctypes.byref(tp), seed, r0, R, dv.ptr(out), ntot + 3, gpu["s"])
+    got = out.cpu().numpy()
+    assert np.all(got[:, ntot:] == 7.0)
+    for b, L in enumerate(Ls):
+        n = sizes[b]
+        for m in range(R):
+            z = _normals(gpu, seed, r0 + m, 5, b, n)
+            ref = L @ z
+            assert np.max(np.abs(got[m, off[b]:off[b] + n] - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref))), (b, m)
+
+
+def test_td_trmm_rng_shared_grid_factor(gpu):
+    """rows_per_real = P: one factor shared by (realisation, pulsar) rows, stream (TDGW, pulsar) - the GWB grid form."""
+    lib, dv = gpu["lib"], gpu["dv"]
+    rng = np.random.default_rng(5)
+    n, P, R = 600, 7, 11
+    L = np.tril(rng.standard_normal((n, n))) / 10 + np.eye(n)
+    keep = []
+    tp, _ = _plan(gpu, [L], [n], P, 6, keep)
+    out = dv.zeros((R * P, n))
+    seed, r0 = 3, 40
+    lib.call("pta_td_trmm_rng", ctypes.byref(tp), seed, r0, R * P, dv.ptr(out), n, gpu["s"])
+    got = out.cpu().numpy().reshape(R, P, n)
+    for r in (0, 5, 10):
+        for a in (0, 3, 6):
+            ref = L @ _normals(gpu, seed, r0 + r, 6, a, n)
+            assert np.max(np.abs(got[r, a] - ref)) < 1e-12 * np.max(np.abs(ref))
+
+
+def _small_array(with_gwb, with_cgw=False, seed=21):
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    rng = np.random.default_rng(seed)
+    Ns = [389, 256, 301]
+    psrs = []
+    for a, N in enumerate(Ns):
+        mjd = np.sort(rng.uniform(53000, 57000, N))
+        mjd[5:8] = mjd[5] + np.array([0.0, 0.01, 0.03])           # a three-TOA epoch
+        flags = [{"f": "A" if x < 0.5 else "B"} for x in rng.uniform(size=N)]
+        p = SimulatedPulsar(toas=ArrayTOAs(mjd, rng.uniform(0.3, 0.8, N), flags=flags), name=f"J{a:02d}",
+                            loc={"RAJ": float(rng.uniform(0, 24)), "DECJ": float(rng.uniform(-60, 60))})
+        make_ideal(p)
+        psrs.append(p)
+    eng = ReplicaEngine(psrs, seed=4242)
+    noise = dict(flags=[["A", "B"]] * 3, efac=[np.array([1.1, 0.9])] * 3, log10_equad=[np.array([-6.6, -6.3])] * 3,
+                 log10_ecorr=[np.array([-6.4, -6.7])] * 3, rn_log10_A=[-13.6, None, -14.1], rn_gamma=[3.1, None, 4.4])
+    eng.set_white_noise(efac=noise["efac"], log10_equad=noise["log10_equad"], flags=noise["flags"])
+    eng.set_jitter(log10_ecorr=noise["log10_ecorr"], flags=noise["flags"], coarsegrain=0.1)
+    eng.set_red_noise(noise["rn_log10_A"], noise["rn_gamma"], components=12)
+    if with_gwb:
+        eng.set_gwb(-14.3, 13. / 3.)
+    if with_cgw:
+        eng.add_cgw(gwtheta=1.1, gwphi=2.5, mc=1e9, dist=15.0, fgw=1e-8, phase0=0.5, psi=1.5, inc=0.7, pdist=1.0, pphase=None,
+                    psrTerm=True, evolve=True, phase_approx=False, tref=53000 * 86400)
+    return eng, psrs, noise
+
+
+def _oracle_covariances(eng, psrs, noise, components=12):
+    covs = []
+    for a, psr in enumerate(psrs):
+        n = int(eng.counts[a])
+        tf = np.array([f["f"] for f in psr.toas.table["flags"].data])
+        sig = eng.sigma_s[a]
+        efv = po.flag_vector(tf, noise["flags"][a], noise["efac"][a], n)
+        eqv = po.flag_vector(tf, noise["flags"][a], 10 ** np.asarray(noise["log10_equad"][a]), n)
+        sigma2 = (efv * sig) ** 2 + (efv * eqv) ** 2
+        epoch_of, ne, first, _ = po.quantize(eng.mjd[a], dt=0.1)
+        ecv = po.jitter_ecorr_vector(ne, first, noise["log10_ecorr"][a], toa_flags=tf, flags=noise["flags"][a])
+        t = eng.tdb_s[a]
+        if noise["rn_log10_A"][a] is None:
+            C = np.diag(sigma2) + (epoch_of[:, None] == epoch_of[None, :]) * (ecv[epoch_of] ** 2)[:, None]
+        else:
+            C = po.td_covariance(t, noise["rn_log10_A"][a], noise["rn_gamma"][a], components, sigma2, epoch_of, ecv)
+        covs.append(C)
+    return covs
+
+
+def test_td_engine_per_pulsar_part_vs_oracle():
+    """prepare_td + generate_td without a GWB: covariance assembly, batched/ragged factorisation and the in-register-draw
+    product of three ragged pulsars (one without red noise) against NumPy on the dumped deviates, 1e-10 relative RMS; the CGW
+    term rides along; replay_td (explicit-operand kernels) gives the same numbers."""
+    eng, psrs, noise = _small_array(False, with_cgw=True)
+    eng.prepare_td()
+    R = 5
+    out = eng.generate_td(R, r0=7).cpu().numpy()
+    covs = _oracle_covariances(eng, psrs, noise)
+    det = eng.d_det.cpu().numpy()
+    draws = [eng.dump_draws_td(7 + r) for r in range(R)]
+    for a in range(3):
+        sl = slice(eng.off[a], eng.off[a + 1])
+        L = eng.td_factor(a).cpu().numpy()
+        Lref = np.linalg.cholesky(covs[a])
+        assert np.max(np.abs(L - Lref)) < 1e-10 * np.max(np.abs(Lref)), a
+        for r in range(R):
+            ref = po.td_draw(covs[a], draws[r]["td"][a]) + det[sl]
+            assert relrms(out[r, sl], ref) < 1e-10, (a, r)
+    rep = eng.replay_td(draws).cpu().numpy()
+    assert np.max(np.abs(rep - out)) < 1e-12 * np.sqrt(np.mean(out ** 2))
+    assert np.array_equal(eng.generate_td(2, r0=9).cpu().numpy(), out[2:4])      # offset / batch independent
+
+
+def test_td_engine_gwb_part():
+    """the GWB of TD mode: grid covariance T^T T against the Toeplitz formula of SURVEY.md App. A.1 (1e-12), its device
+    factor by backward error (1e-12, within 10x of LAPACK's) and by forward error against an 80-bit factorisation (no worse than 20x LAPACK's), and
+    the injected term against the oracle evaluated with the device's own factor (1e-10) and with NumPy's (conditioning-limited)."""
+    eng, psrs, noise = _small_array(True)
+    eng.prepare_td()
+    eng0, _, _ = _small_array(False)
+    eng0.prepare_td()
+    R = 3
+    out = eng.generate_td(R).cpu().numpy()
+    base = eng0.generate_td(R).cpu().numpy()                  # same seed and TD streams: the difference is the GWB term
+    npts = eng.plan.gw_npts
+    grid = po.gwb_grid([float(m.min()) for m in eng.mjd], [float(m.max()) for m in eng.mjd])
+    Cf = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], -14.3, 13. / 3.)
+    S = po.td_gwb_grid_covariance(grid, Cf)
+    Sg = eng.Sg_td[:, :npts].cpu().numpy()
+    il = np.tril_indices(npts)
+    assert np.max(np.abs(Sg[il] - S[il])) < 1e-12 * np.max(np.abs(S))
+    Lg = eng.gw_grid_factor().cpu().numpy()
+    Sdev = np.tril(Sg) + np.tril(Sg, -1).T                       # what the device factored (its own Gram matrix, lower half)
+    Sj = Sdev + eng.gw_td_jitter * np.mean(np.diag(Sdev)) * np.eye(npts)
+    back_dev = np.max(np.abs(Lg @ Lg.T - Sj)) / np.max(np.abs(S))
+    Lnp = np.linalg.cholesky(Sj)
+    back_np = np.max(np.abs(Lnp @ Lnp.T - Sj)) / np.max(np.abs(S))
+    assert back_dev < 1e-12 and back_dev < 10 * back_np + 1e-14, (back_dev, back_np)     # n eps = 1.3e-13 at n = 600
+    Lx = po.cholesky_longdouble(Sj)
+    err_dev = np.max(np.abs(Lg - Lx.astype(np.float64)))
+    err_lapack = np.max(np.abs(np.linalg.cholesky(Sj) - Lx.astype(np.float64)))
+    assert err_dev < 20 * err_lapack + 1e-16 * np.max(np.abs(Lg)), (err_dev, err_lapack)
+    Mchol = np.linalg.cholesky(po.hd_orf_closed_form(po.psr_locs_equatorial([p.loc for p in psrs])))
+    toa_s = [m * 86400 for m in eng.mjd]
+    for r in range(R):
+        d = eng.dump_draws_td(r)
+        zero = [np.zeros((int(n), int(n))) + np.eye(int(n)) for n in eng.counts]
+        gw_dev = po.td_realisation(toa_s, zero, [np.zeros(int(n)) for n in eng.counts], grid=grid, Lg=Lg, M=Mchol, z_gw=d["gwb"])
+        gw_np = po.td_realisation(toa_s, zero, [np.zeros(int(n)) for n in eng.counts], grid=grid, Lg=np.linalg.cholesky(Sj), M=Mchol,
+                                  z_gw=d["gwb"])
+        for a in range(3):
+            sl = slice(eng.off[a], eng.off[a + 1])
+            got = out[r, sl] - base[r, sl]
+            assert relrms(got, gw_dev[a]) < 1e-10, (r, a)
+            assert relrms(got, gw_np[a]) < 1e-3, (r, a)          # two float64 factors of a cond ~ 3e14 matrix
+    rep = eng.replay_td([eng.dump_draws_td(r) for r in range(R)]).cpu().numpy()
+    assert np.max(np.abs(rep - out)) < 1e-12 * np.sqrt(np.mean(out ** 2))
+
+
+def test_td_and_throughput_mode_have_the_same_ensemble_covariance():
+    """TD mode and throughput mode draw from the same Gaussian: sample covariances of 16384 realisations each (two pulsars,
+    RN + EFAC/EQUAD + ECORR + GWB) agree element by element within sampling error, and with the analytic covariance
+    C_a (+ ORF_ab A_a Sigma_g A_b^T for the GWB)."""
+    import torch
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    rng = np.random.default_rng(77)
+    Ns, R = [40, 33], 16384
+    psrs = []
+    for a, N in enumerate(Ns):
+        mjd = np.sort(rng.uniform(53000, 56000, N))
+        p = SimulatedPulsar(toas=ArrayTOAs(mjd, rng.uniform(0.3, 0.6, N)), name=f"J{a}", loc={"RAJ": 3.0 + 7 * a, "DECJ": 10.0 - 30 * a})
+        make_ideal(p)
+        psrs.append(p)
+    eng = ReplicaEngine(psrs, seed=31)
+    eng.set_white_noise(efac=1.1, log10_equad=-6.5)
+    eng.set_jitter(log10_ecorr=-6.4, coarsegrain=0.1)
+    eng.set_red_noise([-13.2, -13.5], [2.5, 3.5], components=5)
+    eng.set_gwb(-13.3, 13. / 3.)
+    eng.prepare_td()
+    x_td = eng.generate_td(R)
+    x_fd = eng.generate(R)
+    c_td = (x_td.T @ x_td / R).cpu().numpy()
+    c_fd = (x_fd.T @ x_fd / R).cpu().numpy()
+    # analytic covariance
+    n = eng.n_toa
+    Cm = np.zeros((n, n))
+    grid = po.gwb_grid([float(m.min()) for m in eng.mjd], [float(m.max()) for m in eng.mjd])
+    Cf = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], -13.3, 13. / 3.)
+    S = po.td_gwb_grid_covariance(grid, Cf)
+    orf = po.hd_orf_closed_form(po.psr_locs_equatorial([p.loc for p in psrs]))
+    A = []
+    for a in range(2):
+        Aa = np.stack([po.lerp_sorted(grid["ut"], e, eng.mjd[a] * 86400) for e in np.eye(grid["npts"])], axis=1)   # [N_a, npts]
+        A.append(Aa)
+    for a in range(2):
+        sa = slice(eng.off[a], eng.off[a + 1])
+        epoch_of, ne, first, _ = po.quantize(eng.mjd[a], dt=0.1)
+        sig2 = (1.1 * eng.sigma_s[a]) ** 2 + (1.1 * 10 ** -6.5) ** 2
+        Cm[sa, sa] = po.td_covariance(eng.tdb_s[a], [-13.2, -13.5][a], [2.5, 3.5][a], 5, sig2, epoch_of, np.full(ne, 10 ** -6.4))
+        for b in range(2):
+            sb = slice(eng.off[b], eng.off[b + 1])
+            Cm[sa, sb] += orf[a, b] * (A[a] @ S @ A[b].T)
+    d = np.sqrt(np.diag(Cm))
+    for emp in (c_td, c_fd):
+        assert np.max(np.abs(emp - Cm) / np.outer(d, d)) < 6.0 / np.sqrt(R)
+    assert abs(np.trace(c_td) / np.trace(c_fd) - 1) < 0.03
+
+
+def test_td_headline_size_vs_numpy():
+    """N = 5000 TOAs, two pulsars with the ng15 noise values of config 3: covariance, factor and L.z against NumPy / LAPACK at
+    1e-10 (the size BASELINE.json's metric is quoted on; LAPACK's potrf of a 5000^2 takes about a second)."""
+    from pta_replicator_amd.engine import ReplicaEngine
+    from bench import configure_engine, headline_array
+    psrs, noise = headline_array(2, 5000)
+    eng = configure_engine(ReplicaEngine(psrs, seed=5), noise)
+    eng._gw = None
+    eng.prepare_td()
+    R = 3
+    out = eng.generate_td(R).cpu().numpy()
+    covs = _oracle_covariances(eng, psrs, noise, components=30)
+    for a in range(2):
+        n, ld = int(eng.counts[a]), eng.td_ld[a]
+        Lref = np.linalg.cholesky(covs[a])
+        L = eng.td_factor(a).cpu().numpy()
+        assert np.max(np.abs(L - Lref)) < 1e-10 * np.max(np.abs(Lref)), a
+        sl = slice(eng.off[a], eng.off[a + 1])
+        for r in range(R):
+            z = eng.dump_draws_td(r)["td"][a]
+            assert relrms(out[r, sl], Lref @ z) < 1e-10, (a, r)
+    # the covariance itself (lower triangle) as the device assembled it: re-assemble into a scratch buffer
+    import torch
+    from pta_replicator_amd import _lib, device as dv
+    a, n = 1, 5000
+    Cd = dv.zeros((n, n))
+    o = int(eng.off[a])
+    phi = (eng.d_amp ** 2).contiguous()
+    ec2 = (eng.d_ecorr_toa ** 2).contiguous()
+    _lib.call("pta_td_cov_assemble", ctypes.c_void_p(eng.d_Ft.data_ptr() + 8 * o), eng.n_toa, n, eng.K, ctypes.c_void_p(phi.data_ptr() + 8 * a * eng.K),
+              ctypes.c_void_p(eng._td_sigma2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_epoch_of.data_ptr() + 4 * o),
+              ctypes.c_void_p(ec2.data_ptr() + 8 * o), dv.ptr(Cd), n, dv.stream_ptr())
+    il = np.tril_indices(n)
+    assert np.max(np.abs(Cd.cpu().numpy()[il] - covs[a][il])) < 1e-10 * np.max(np.abs(covs[a]))
