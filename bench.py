@@ -3,20 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W [--batch R]
 
-A "step" is one pass of the hot path over one batch of R realisations of the whole array, every Gaussian deviate
-drawn on chip, inputs resident in HBM (ReplicaEngine.generate: pta_engine_rn_coef -> pta_gwb_idft_rng ->
-pta_gwb_mix -> pta_engine_synth).  N > 1: launched by torch.distributed.run, one rank per GPU; realisations are
-independent, so rank g generates realisations [g*R*K .. ) of the same seeded stream (weak scaling, no data-path
-collective; the north_star's gather of the residual arrays to rank 0 is timed separately and reported as
-`gather_ms`, not folded into the step).  Rank 0 prints ONE JSON line.
+Workload = BASELINE.json config 3 as SURVEY.md §8d specifies it (headline_array): the 68 pulsars of ng15_dict.json with their
+per-backend EFAC / t2EQUAD / ECORR and red-noise values, HD GWB at the dictionary's gw_log10_A, 1024 realisations per step.
+A "step" is one pass of the hot path over one batch of R realisations of the whole array, every Gaussian deviate drawn on
+chip, inputs resident in HBM (ReplicaEngine.generate = one pta_engine_generate call: pta_engine_rn_coef -> pta_gwb_czt ->
+pta_gwb_mix -> pta_engine_synth).  N > 1: launched by torch.distributed.run, one rank per GPU; realisations are independent,
+so rank g generates realisations [g*R*(K+W) .. ) of the same seeded stream (weak scaling, no data-path collective).  The
+north_star's gather of the residual arrays to rank 0 is timed separately as a pipelined generate+gather
+(`gathered_to_rank0`), not folded into the step.  Rank 0 prints ONE JSON line.
 
 Besides the contract fields the line carries
-  roofline      the dominant kernel of the step against its bound (algorithmic units per launch / measured
-                launch time; HBM peak 8 TB/s from MI355X_MICROARCH.md, fp64 matrix peak 78.6 TFLOP/s = AMD's
-                public MI355X figure, cross-checked by the in-library microbenchmark)
-  kernels       per-kernel times of one step (HIP events on the launch stream)
-  cpu_baseline  the CPU oracle (a NumPy port of the reference's algebra, oracle/pta_oracle.py) timed on this
-                host for one realisation of the same workload, with the reference's dense-U ECORR
+  roofline      the dominant kernel of the step against its bound: algorithmic units per launch / launch time measured
+                here with HIP events on the launch stream; HBM peak 8 TB/s (MI355X_MICROARCH.md); fp64 matrix peak
+                78.6 TFLOP/s = AMD's public MI355X figure, cross-checked by the in-library microbenchmark.  `traffic`
+                (PMC HBM bytes per launch) comes from the committed rocprofv3 passes in profiles/r02_pmc.json and is
+                quoted only while launch shape and kernel sources match that profile - otherwise null with the reason
+  kernels_ms    per-kernel times of one step (HIP events)
+  td_mode       the dense path of the north_star on the same array: covariance assembly, batched fp64 Cholesky
+                (TFLOP/s, MFMA-busy %), whole-array realisations/s of generate_td
+  cpu_baseline  oracle/cpu_baseline.py on the host cores (subprocess; BLAS threads 1 and all): the unmodified reference
+                under stubs where /root/reference is mounted (kind "reference"), else the NumPy port (kind "port")
 """
 import argparse
 import json
@@ -31,12 +37,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD public MI355X fp64 matrix (= vector) figure (not in the local guide)
-# HBM bytes per launch from the PMC passes of the same command (scripts/gpu_profile.sh -> profiles/), KiB as rocprofv3 reports them;
-# FETCH_SIZE is uncorrected (MI355X_MICROARCH.md: it under-counts wide streaming reads by up to 2x on gfx950)
-# insts_valu = SQ_INSTS_VALU (wave instructions) per launch, valu_busy = VALUBusy from the stall-counter pass of the same
-# summary file: the kernel is VALU-issue bound
-PMC_TRAFFIC = {"pta_engine_synth": {"R": 960, "n_toa": 340000, "fetch_kib": 361309.0, "write_kib": 2669630.0, "insts_valu": 1.44648e9, "valu_busy": 0.769,
-                                    "source": "profiles/r01_rocprofv3_summary_run81.txt"}}
 
 
 def ng15_noise():
@@ -95,106 +95,135 @@ def build_engine(P, N, seed):
     return eng, psrs, noise
 
 
-def cpu_baseline(psrs, noise, repeats=1):
-    """One realisation of the same workload through the CPU oracle, the way the reference spends its time:
-    everything (ORF, design matrices, dense ECORR U) rebuilt per call.  Returns dict for the JSON line."""
-    from oracle import pta_oracle as po
-    P = len(psrs)
-    mjd = [np.asarray(p.toas.get_mjds().value, dtype=np.float64) for p in psrs]
-    tdb = [p.toas.table["tdbld"] for p in psrs]
-    sig = [np.asarray(p.toas.get_errors().to("s").value) for p in psrs]
-    locs = po.psr_locs_equatorial([p.loc for p in psrs])
-    parts = {}
-
-    def run(dense_u):
-        t0 = time.perf_counter()
-        grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd])
-        ORF = po.gwb_orf(locs)                      # pair loop in Python, like spharmORFbasis.correlated_basis
-        M = np.linalg.cholesky(ORF)
-        w = po.gwb_draws(16672, P, grid["Nf"])
-        C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], noise["gw_log10_A"], 13. / 3.)
-        po.gwb_dt(grid, M, w, C, [m * 86400 for m in mjd])
-        t1 = time.perf_counter()
-        for a in range(P):
-            if noise["rn_log10_A"][a] is not None:
-                (zr,) = po.legacy_normals(19870 + a, [60])
-                po.red_noise_dt(tdb[a], noise["rn_log10_A"][a], noise["rn_gamma"][a], zr)
-        t2 = time.perf_counter()
-        for a in range(P):
-            n = len(mjd[a])
-            z1, z2 = po.legacy_normals(10660 + a, [n, n])
-            po.measurement_noise_dt(sig[a], np.ones(n) * noise["efac"][a], np.ones(n) * 10 ** noise["log10_equad"][a], z1, z2)
-        t3 = time.perf_counter()
-        for a in range(P):
-            epoch_of, ne, first, _ = po.quantize(mjd[a], dt=0.1)
-            (ze,) = po.legacy_normals(17763 + a, [ne])
-            ecv = po.jitter_ecorr_vector(ne, first, noise["log10_ecorr"][a])
-            if dense_u:   # white_noise.py:37-39,182: dense N x E indicator matrix and matvec
-                U = np.zeros((len(mjd[a]), ne), "d")
-                U[np.arange(len(mjd[a])), epoch_of] = 1
-                np.dot(U * ecv, ze)
-            else:
-                po.jitter_dt(epoch_of, ecv, ze)
-        t4 = time.perf_counter()
-        return dict(gwb=t1 - t0, rn=t2 - t1, wn=t3 - t2, ecorr=t4 - t3, total=t4 - t0)
-
-    runs = [run(True) for _ in range(max(2, repeats))]       # ~14 s of single-core work: the bounded sample
-    dense = {k: float(np.mean([r[k] for r in runs])) for k in runs[0]}
-    gather = run(False)
-    return {"value": 1.0 / dense["total"], "unit": "realisations/s", "cores": 1, "kind": "port",
-            "sample": f"{len(runs)} realisations of the same {P} psr x {len(mjd[0])} TOA workload (GWB+RN+EFAC/EQUAD+ECORR) through "
-                      f"oracle/pta_oracle.py, reference-style dense-U ECORR, everything rebuilt per call like the reference; "
-                      f"NumPy BLAS threads = default, Python loop single-threaded",
-            "seconds": {k: round(v, 4) for k, v in dense.items()},
-            "value_ecorr_as_gather": 1.0 / gather["total"],
-            "host_cpus": os.cpu_count()}
+def src_sha(*files):
+    """sha256 over the kernel sources a profile was taken with: a PMC figure in profiles/*.json is only quoted while the
+    sources that produced it are unchanged."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "pta_replicator_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
-def td_mode_numbers(N, B, R):
-    """Secondary metric of BASELINE.json: the dense time-domain path (no counterpart in the reference) - covariance
-    assembly GB/s, blocked fp64 Cholesky TFLOP/s (MFMA trailing update) and L.Z TFLOP/s for B pulsars of N TOAs."""
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_mfma.h")
+TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_mfma.h")
+
+
+def pmc_entry(key, srcs, **shape):
+    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r2.sh -> profiles/r02_pmc.json),
+    or (None, reason) when the file is missing, was taken at another launch shape, or the kernel sources changed since."""
+    try:
+        with open(PMC_FILE) as fh:
+            e = json.load(fh)[key]
+    except (OSError, KeyError, ValueError):
+        return None, "no committed PMC profile for this kernel"
+    if any(e.get(k) != v for k, v in shape.items()):
+        return None, f"PMC profile was taken at another launch shape ({ {k: e.get(k) for k in shape} })"
+    if e.get("src_sha") != src_sha(*srcs):
+        return None, "kernel sources changed since the PMC profile was taken (stale)"
+    return e, None
+
+
+def dump_workload(psrs, noise, path):
+    """the bench workload as plain arrays for oracle/cpu_baseline.py (a separate process: its BLAS thread count is set by
+    the environment, and the reference's dependency stubs never enter this process)."""
+    names = [p.name for p in psrs]
+    mjd = np.stack([np.asarray(p.toas.get_mjds().value, dtype=np.float64) for p in psrs])
+    which = np.stack([np.array([noise["flags"][a].index(f["f"]) for f in p.toas.table["flags"].data], dtype=np.int32) for a, p in enumerate(psrs)])
+    nj = {k: ([None if x is None else (x.tolist() if hasattr(x, "tolist") else x) for x in v] if isinstance(v, list) else v) for k, v in noise.items()}
+    np.savez(path, names=np.array(names), mjd=mjd, which=which, raj=np.array([p.loc["RAJ"] for p in psrs]),
+             decj=np.array([p.loc["DECJ"] for p in psrs]), noise_json=np.array(json.dumps(nj)))
+
+
+def cpu_baseline(psrs, noise, subset=8, repeats=3):
+    """oracle/cpu_baseline.py twice - BLAS threads = 1 and = all host cores - on a bounded sample of the same workload
+    (whole-array add_gwb + the per-pulsar calls of `subset` pulsars scaled to the array; one warm-up + `repeats` timed
+    repeats each).  kind = "reference" (the unmodified reference under stubs) where /root/reference is mounted, else "port"."""
+    import subprocess
+    import tempfile
+    ncpu = os.cpu_count() or 1
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "workload.npz")
+        dump_workload(psrs, noise, path)
+        for label, nt in (("single_thread", 1), ("all_cores", ncpu)):
+            env = dict(os.environ, OPENBLAS_NUM_THREADS=str(nt), OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), path, "--subset", str(subset), "--repeats",
+                                  str(repeats)], env=env, capture_output=True, text=True, timeout=600)
+            if out.returncode != 0:
+                raise RuntimeError(f"oracle/cpu_baseline.py failed: {out.stderr[-400:]}")
+            res[label] = json.loads(out.stdout.strip().splitlines()[-1])
+            res[label]["threads"] = nt
+    best = min(res.values(), key=lambda r: r["seconds_per_realisation"])
+    P, N = len(psrs), len(psrs[0].toas.get_mjds().value)
+    return {"value": 1.0 / best["seconds_per_realisation"], "unit": "realisations/s", "cores": best["threads"], "kind": best["kind"],
+            "sample": f"{best['repeats']} timed repeats after one warm-up of: add_gwb over all {P} pulsars x {N} TOAs + add_measurement_noise / add_jitter "
+                      f"(reference-style dense-U ECORR) / add_red_noise on {best['subset']} pulsars, scaled x{P}/{best['subset']}; median; "
+                      f"{'unmodified reference functions under the stubs of oracle/run_reference.py (numeric core, PINT sink excluded)' if best['kind'] == 'reference' else 'NumPy port oracle/pta_oracle.py (/root/reference is not mounted on this host)'}",
+            "single_thread": {k: res["single_thread"][k] for k in ("seconds_per_realisation", "seconds_runs", "seconds_without_ecorr", "seconds_parts_last_run", "threads")},
+            "all_cores": {k: res["all_cores"][k] for k in ("seconds_per_realisation", "seconds_runs", "seconds_without_ecorr", "seconds_parts_last_run", "threads")},
+            "value_without_ecorr": 1.0 / best["seconds_without_ecorr"], "host_cpus": ncpu}
+
+
+def td_mode_numbers(eng, R):
+    """BASELINE.json's secondary metric on the SAME array: the dense time-domain path (no counterpart in the reference) -
+    covariance assembly, batched blocked fp64 Cholesky (MFMA trailing update), then whole-array realisations/s of generate_td
+    (L.z with in-register deviates + GWB grid factor + interpolation)."""
     import ctypes
     import torch
     from pta_replicator_amd import _lib, device as dv
+
+    def wall(fn, reps=1):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    t_first = wall(eng.prepare_td)
+    counts = [int(c) for c in eng.counts]
     s = dv.stream_ptr()
-    nm = 30
-    rng = np.random.default_rng(5)
-    t = np.sort(rng.uniform(53000, 58478, N)) * 86400.0
-    Tspan = t.max() - t.min()
-    f = np.arange(1, nm + 1) / Tspan
-    freqs = np.repeat(f, 2)
-    phi = (10 ** -14.0) ** 2 * (freqs * 365.25 * 86400) ** (-3.0) / (12 * np.pi ** 2 * Tspan) * (365.25 * 86400) ** 3
-    from pta_replicator_amd.white_noise import epoch_map
-    epoch_of, first = epoch_map(t / 86400.0, 0.1)
-    t_d, f_d, phi_d = dv.f64(t), dv.f64(f), dv.f64(phi)
-    sig_d, ep_d, ec_d = dv.f64(np.full(N, 0.25e-12)), dv.i32(epoch_of), dv.f64(np.full(N, 4e-14))
-    Ft = dv.empty((2 * nm, N))
-    _lib.call("pta_rn_basis", dv.ptr(t_d), N, 0.0, dv.ptr(f_d), None, nm, 0, dv.ptr(Ft), N, s)
-    C = dv.zeros((B, N, N))
-    info = dv.zeros((B,), dtype=torch.int32)
+    phi = (eng.d_amp ** 2).contiguous()
+    ec2 = (eng.d_ecorr_toa ** 2).contiguous()
 
     def assemble():
-        for b in range(B):
-            _lib.call("pta_td_cov_assemble", dv.ptr(Ft), N, N, 2 * nm, dv.ptr(phi_d), dv.ptr(sig_d), dv.ptr(ep_d), dv.ptr(ec_d),
-                      ctypes.c_void_p(C.data_ptr() + 8 * b * N * N), N, s)
+        for a, n in enumerate(counts):
+            o = int(eng.off[a])
+            _lib.call("pta_td_cov_assemble", ctypes.c_void_p(eng.d_Ft.data_ptr() + 8 * o), eng.n_toa, n, eng.K, ctypes.c_void_p(phi.data_ptr() + 8 * a * eng.K),
+                      ctypes.c_void_p(eng._td_sigma2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_epoch_of.data_ptr() + 4 * o),
+                      ctypes.c_void_p(ec2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_Ltd.data_ptr() + 8 * int(eng.td_pos[a])), eng.td_ld[a], s)
 
-    def wall(fn):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize()
-        return time.perf_counter() - t0
-
-    assemble()
-    ta = wall(assemble)
-    tp = wall(lambda: _lib.call("pta_potrf_batched", dv.ptr(C), N, B, dv.ptr(info), s))
-    ok = int(info.abs().sum().item()) == 0
-    z, out = dv.empty((R, N)), dv.empty((R, N))
-    _lib.call("pta_rng_fill_normal", 1, 0, R, (5 << 24), N // 2, 1, dv.ptr(z), None, N, s)
-    _lib.call("pta_td_trmm", dv.ptr(C), N, N, dv.ptr(z), N, R, dv.ptr(out), N, 0, s)
-    tt = wall(lambda: _lib.call("pta_td_trmm", dv.ptr(C), N, N, dv.ptr(z), N, R, dv.ptr(out), N, 0, s))
-    potrf_tf = N ** 3 / 3.0 * B / tp / 1e12
-    return {"n_toa": N, "n_psr": B, "positive_definite": ok,
-            "cov_assemble_GBps": 8.0 * N * (N + 64) / 2 * B / ta / 1e9,
-            "potrf_TFLOPs": potrf_tf, "potrf_frac_of_fp64_mfma_peak": potrf_tf / FP64_MFMA_PEAK_TFLOPS, "potrf_ms": tp * 1e3,
-            "trmm_TFLOPs_executed": 2.0 * N * N * R / tt / 1e12, "trmm_realisations_per_s_per_pulsar": R / tt}
+    uniform = len(set(counts)) == 1
+    res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_first * 1e3}
+    flop_chol = sum(n ** 3 for n in counts) / 3.0
+    if uniform:
+        n, ld, P = counts[0], eng.td_ld[0], eng.P
+        info = dv.zeros((P,), dtype=torch.int32)
+        ts = []
+        for _ in range(2):
+            ta = wall(assemble)
+            ts.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
+        tp = min(ts)
+        res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_GBps_lower_triangle": 8.0 * sum(n * (n + 64) / 2 for n in counts) / ta / 1e9,
+                    "potrf_ms": tp * 1e3, "potrf_TFLOPs": flop_chol / tp / 1e12, "potrf_frac_of_fp64_mfma_peak": flop_chol / tp / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                    "positive_definite": int(info.abs().sum().item()) == 0})
+    out = dv.empty((R, eng.n_toa))
+    eng.generate_td(R, out=out)
+    t = wall(lambda: eng.generate_td(R, out=out), 2)
+    flop = float(sum(n * n for n in counts))       # useful flops per realisation of L.z (triangular): sum N_a^2
+    res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
+                "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "gw_grid_factor_jitter": eng.gw_td_jitter if eng.plan.gw_npts else None})
+    for key, name in (("k_dgemm_mfma128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng", "trmm_mfma_busy_pct")):
+        e, why = pmc_entry(key, TD_SRC, n_psr=eng.P)
+        res[name] = e["mfma_busy_pct"] if e else None
+        if e:
+            res[name + "_source"] = e.get("source")
+        else:
+            res[name + "_note"] = why
+    return res
 
 
 def main():
@@ -202,12 +231,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=960, help="realisations per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="realisations per step per GPU (BASELINE.json config 3: 1024)")
     ap.add_argument("--psr", type=int, default=68)
     ap.add_argument("--toa", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-td", action="store_true", help="skip the TD-mode (dense covariance / Cholesky / L.z) side measurement")
-    ap.add_argument("--gather", action="store_true", help="also time the gather of the residual arrays to rank 0")
+    ap.add_argument("--no-td", action="store_true", help="skip the TD-mode (dense covariance / Cholesky / L.z) measurement")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the timed generate+gather-to-rank-0 pipeline")
     args = ap.parse_args()
 
     import torch
@@ -221,6 +250,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
+    import ctypes
     from pta_replicator_amd import _lib, device as dv
     eng, psrs, noise = build_engine(args.psr, args.toa, seed=20260921)
     R, K, W = args.batch, args.steps, args.warmup
@@ -232,38 +262,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
-        eng.generate(R, r0=base + i * R, out=out)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(K):
-        eng.generate(R, r0=base + (W + i) * R, out=out)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_steps():
+        for i in range(W):
+            eng.generate(R, r0=base + i * R, out=out)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            eng.generate(R, r0=base + (W + i) * R, out=out)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
 
-    # ---- the same K steps with the opt-in fp32 Gaussian transform (secondary number; `value` stays the fp64-accurate one) ----
-    _lib.call("pta_set_rng_math", 1)
-    eng.generate(R, r0=base, out=out)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(K):
-        eng.generate(R, r0=base + (W + i) * R, out=out)
-    barrier()
-    elapsed_fast = time.perf_counter() - t0
-    _lib.call("pta_set_rng_math", 0)
-    if world > 1:
-        t = torch.tensor([elapsed_fast], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed_fast = float(t.item())
+    elapsed = timed_steps()
+    # ---- secondary numbers, same K steps: (i) opt-in fp32 Gaussian transform; (ii) GWB drawn on the npts-sample grid through the
+    # factor of its covariance (npts instead of 2 Nf normals per pulsar; same distribution, not replayable
+    # through the reference's frequency-domain algebra).  `value` stays the default: fp64 transform, reference-order draws.
+    eng.rng_fast = 1
+    elapsed_fast = timed_steps()
+    eng.rng_fast = 0
+    eng.gwb_mode = "grid"
+    elapsed_grid = timed_steps()
+    eng.gwb_mode = "fourier"
 
     # ---- per-kernel times of one step: HIP events on the stream the kernels are launched on ----
     kern = {}
     s = dv.stream_ptr()
     ws = eng.workspace(R)
+    eng.generate(R, r0=base, out=out)          # fills the workspace pointers of the plan
     npts, Nf, P = eng.plan.gw_npts, eng.grid["Nf"], eng.P
 
     def timed(name, fn, reps=3):
@@ -277,22 +306,30 @@ def main():
         torch.cuda.synchronize()
         kern[name] = ev[0].elapsed_time(ev[1]) / reps
 
-    import ctypes
-    timed("pta_engine_rn_coef", lambda: _lib.call("pta_engine_rn_coef", eng.seed, 0, R, P, eng.K, dv.ptr(eng.d_amp), dv.ptr(ws["coef"]), s))
-    timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts, s))
+    timed("pta_engine_rn_coef", lambda: _lib.call("pta_engine_rn_coef", eng.seed, 0, R, P, eng.K, dv.ptr(eng.d_amp), dv.ptr(ws["coef"]), 0, s))
+    timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts,
+                                                eng.idft_variant, 0, s))
     if eng.use_czt:
-        timed("pta_gwb_czt", lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, s))
-    timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), s))
+        timed("pta_gwb_czt", lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, 0, 0, s))
+    timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), 0, s))
     timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
 
-    gather_ms = None
-    if args.gather and world > 1:
-        from pta_replicator_amd.distributed import gather_to_rank0
-        barrier()
-        tg = time.perf_counter()
-        gather_to_rank0(out)
-        barrier()
-        gather_ms = (time.perf_counter() - tg) * 1e3
+    gathered = None
+    if world > 1 and not args.no_gather:   # the north_star's gather of the residual arrays to rank 0, pipelined with generation
+        try:
+            from pta_replicator_amd.distributed import generate_gathered
+            full = generate_gathered(eng, world * R, r0=0, chunk=256)      # warm-up (allocations, RCCL channels)
+            del full
+            barrier()
+            tg = time.perf_counter()
+            full = generate_gathered(eng, world * R, r0=0, chunk=256)
+            barrier()
+            tg = time.perf_counter() - tg
+            gathered = {"realisations": world * R, "ms": tg * 1e3, "realisations_per_s": world * R / tg,
+                        "note": "every rank generates its shard in chunks of 256 while the previous chunk travels; rank 0 receives straight into the final tensor"}
+            del full
+        except Exception as e:  # pragma: no cover
+            gathered = {"error": str(e)[:300]}
 
     if rank != 0:
         if world > 1:
@@ -314,14 +351,17 @@ def main():
         ach = alg_bytes / (kern[k] * 1e-3) / 1e9
         d = {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": None, "avg_launch_ms": kern[k]}
-        t = PMC_TRAFFIC.get(k)
-        if t and t["R"] == R and t["n_toa"] == eng.n_toa:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) of this very launch shape
-            d["traffic"] = (t["fetch_kib"] + t["write_kib"]) * 1024.0
-            d["traffic_source"] = t["source"]
-            if "insts_valu" in t:   # 4 issue cycles per wave64 VALU instruction, 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
-                issue_ms = t["insts_valu"] * 4.0 / (256 * 4) / 2.4e9 * 1e3
-                d["valu_issue"] = {"insts_valu": t["insts_valu"], "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k],
-                                   "valu_busy_pmc": t.get("valu_busy")}   # SQ_ACTIVE_INST_VALU / CU_NUM / GRBM_GUI_ACTIVE, same profile
+        e, why = pmc_entry("k_engine_synth_mfma<false>", SYNTH_SRC, R=R, n_toa=eng.n_toa)
+        if e:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) of this very launch shape and these very sources
+            d["traffic"] = (e["fetch_kib"] + e["write_kib"]) * 1024.0
+            d["traffic_source"] = e.get("source")
+            d["traffic_note"] = "FETCH_SIZE uncorrected (gfx950 under-counts wide streaming reads by up to 2x, MI355X_MICROARCH.md)"
+            if "insts_valu" in e:   # 4 issue cycles per wave64 VALU instruction, 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+                issue_ms = e["insts_valu"] * 4.0 / (256 * 4) / 2.4e9 * 1e3
+                d["valu_issue"] = {"insts_valu": e["insts_valu"], "insts_valu_per_output_element": e["insts_valu"] * 64.0 / (R * eng.n_toa),
+                                   "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k], "valu_busy_pmc": e.get("valu_busy")}
+        else:
+            d["traffic_note"] = why
         return d
 
     def flop_roof(k):
@@ -342,40 +382,45 @@ def main():
         roof["alternative_gwb_transform"] = flop_roof("pta_gwb_idft_rng")
 
     micro = {}
-    try:
-        if world > 1:   # the scaling runs only need the headline number; microbench / TD mode are N=1 extras
-            raise RuntimeError("skipped at N>1")
-        res = ctypes.c_double(0.0)
-        for kind, name in ((0, "fp64_mfma_tflops"), (1, "fp64_fma_tflops"), (2, "hbm_write_TBps"), (4, "normals_T_per_s")):
-            _lib.call("pta_microbench", kind, 1 << 30, 2000 if kind in (0, 1) else (20 if kind == 2 else 200), ctypes.byref(res))
-            micro[name] = round(res.value, 3)
-    except Exception as e:  # pragma: no cover
-        micro["error"] = str(e)
+    if world == 1:   # the scaling runs only need the headline number; microbench / TD mode / CPU baseline are N = 1 extras
+        try:
+            res = ctypes.c_double(0.0)
+            for kind, name in ((0, "fp64_mfma_tflops"), (1, "fp64_fma_tflops"), (2, "hbm_write_TBps"), (4, "normals_T_per_s")):
+                _lib.call("pta_microbench", kind, 1 << 30, 2000 if kind in (0, 1) else (20 if kind == 2 else 200), 0, ctypes.byref(res))
+                micro[name] = round(res.value, 3)
+        except Exception as e:  # pragma: no cover
+            micro["error"] = str(e)
 
     td = None
     if not args.no_td and world == 1:
         try:
-            td = td_mode_numbers(args.toa, args.psr, 512)   # the whole array: 68 x 5000^2 fp64 = 13.6 GB of covariance
+            td = td_mode_numbers(eng, 1024)   # the whole array: 68 x 5000^2 fp64 = 13.6 GB of factors
         except Exception as e:  # pragma: no cover
-            td = {"error": str(e)}
+            td = {"error": str(e)[:300]}
 
     line = {
         "metric": "realizations/sec, 68 psr x 5000 TOAs GWB+RN+WN", "value": world * R * K / elapsed, "unit": "realizations/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.psr} pulsars x {args.toa} TOAs synthetic array (BASELINE.json config 3 geometry): HD GWB + per-pulsar "
-                               f"power-law RN (30 components) + EFAC/EQUAD + ECORR, on-chip Philox draws, {R} realisations per step per GPU",
+        "config": {"workload": f"BASELINE.json config 3: the {args.psr} pulsars of ng15_dict.json x {args.toa} synthetic TOAs - HD GWB (gw_log10_A of the dict) + "
+                               f"per-pulsar power-law RN (dict values, 30 components) + per-backend EFAC / t2EQUAD / ECORR (dict values), on-chip Philox "
+                               f"draws, {R} realisations per step per GPU",
                    "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
         "value_fast_rng_math": world * R * K / elapsed_fast,
+        "value_gwb_grid_draws": world * R * K / elapsed_grid,
         "roofline": roof, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
     }
     if td is not None:
         line["td_mode"] = td
-    if gather_ms is not None:
-        line["gather_ms"] = gather_ms
+    if gathered is not None:
+        line["gathered_to_rank0"] = gathered
     if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(psrs, noise)
-        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+        try:
+            line["cpu_baseline"] = cpu_baseline(psrs, noise)
+            line["gpu_over_cpu"] = {"with_reference_dense_U_ecorr": line["value"] / line["cpu_baseline"]["value"],
+                                    "without_ecorr": line["value"] / line["cpu_baseline"]["value_without_ecorr"]}
+        except Exception as e:  # pragma: no cover
+            line["cpu_baseline"] = {"error": str(e)[:400]}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

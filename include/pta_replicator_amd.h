@@ -18,6 +18,9 @@
  *    `accumulate` = 0 overwrites `out`, 1 adds into it.
  *  - Everything is IEEE binary64, like the reference (it casts PINT's longdouble columns to
  *    float64 before any arithmetic: red_noise.py:123, :287).
+ *  - No process-wide state: every option that changes what a call computes or how (Gaussian-transform mode, kernel
+ *    variants) is an argument or a field of the plan struct passed to that call, so concurrent callers on different
+ *    streams / threads cannot influence each other (ABI 2; ABI 1 had pta_set_* switches).
  */
 #ifndef PTA_REPLICATOR_AMD_H
 #define PTA_REPLICATOR_AMD_H
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 1
+#define PTA_ABI_VERSION 2
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -47,9 +50,10 @@ int pta_device_info(int *cu_count, int *wavefront, char *arch, int arch_len);
  * deviate is Philox-4x32-10(key = seed, counter = (pair, stream, realisation)) + Box-Muller.
  * stream ids: (kind << 24) | pulsar, kind = 1 GWB, 2 RN, 3 WN, 4 ECORR, 5 TD (N_a x N_a factor), 6 TDGW (GWB grid factor). */
 
-/* Gaussian transform used by every on-chip draw (process-wide): 0 (default) = fp64 Box-Muller with < 1 ulp log / sincos,
- * 1 = "fast RNG math": the same uniforms through the hardware fp32 log / sqrt / sin / cos (deviates accurate to ~1e-6).  */
-int pta_set_rng_math(int fast);
+/* `rng_fast` (argument or plan field of every call that draws on chip) selects the Gaussian transform: 0 (default) = fp64
+ * Box-Muller with < 1 ulp log / sincos, 1 = "fast RNG math": the same uniforms through the hardware fp32 log / sqrt / sin /
+ * cos (deviates accurate to ~1e-6).  It is part of what defines realisation r: all ranks of a job must use the same value
+ * (pta_replicator_amd.distributed checks).                                                                              */
 
 /* Known-answer access to the raw generator: out[i] = 4 x u32 of
  * Philox4x32-10(counter = ctr[i][0..3], key = key[0..1]).  ctr/key/out are device u32.   */
@@ -60,7 +64,7 @@ int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int n, uint32_t
  *   interleave = 0: z0[r*ld + p] = first, z1[r*ld + p] = second deviate of pair p
  * for pairs p in [0, npairs), realisations r0 .. r0+R-1.                                   */
 int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t stream_id, int npairs, int interleave,
-                        double *z0, double *z1, int64_t ld, void *stream);
+                        double *z0, double *z1, int64_t ld, int rng_fast, void *stream);
 
 /* ---------------------------------------------------------------- red noise -------- */
 /* Fourier design matrix, transposed: Ft[c*N + i] = column c of F for TOA i.
@@ -124,13 +128,12 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
  * launch on `stream` (A/B timing).                                                                                  */
 #define PTA_POTRF_ZERO_UPPER 1
 #define PTA_POTRF_NO_LOOKAHEAD 2
+#define PTA_POTRF_VALU 8          /* cross-check: VALU reference GEMM and substitution panel solve instead of the MFMA kernels */
 #define PTA_POTRF_SUBSTITUTION 4  /* panel solves by forward substitution instead of the MFMA product with the inverted diagonal
                                      block: LAPACK-grade backward error also when the diagonal blocks are very ill-conditioned
                                      (cond(L11) * eps enters the product form) - used for the GWB grid covariance, cond ~ 3e14 */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
-/* debug/validation knob: 1 (default) = MFMA GEMM inside potrf / mix / trmm, 0 = VALU reference GEMM */
-int pta_set_gemm_algo(int algo);
 
 /* ---------------------------------------------------------------- GWB -------------- */
 /* The reference's chain (red_noise.py:238-287): w -> M@w -> *sqrt(C), zero DC/Nyquist -> Hermitian
@@ -155,15 +158,14 @@ int pta_gwb_idft(const double *w, int64_t ldw, int M, int Nf, const double *T, i
  * mirror symmetry exploited:  x[c + j'] = E - O, x[c - j'] = E + O  around the window centre c, which
  * halves the flops.  pta_gwb_twiddle_sym lays the half-window twiddles out slab by slab exactly as the
  * kernel stages them through LDS (Tsym) plus the per-bin rotation e^{2 pi i c k / n} (rot); sizes in doubles
- * come from pta_gwb_twiddle_sym_size.  pta_set_idft_variant selects the column tiling of a workgroup:
- * 0 = 19 tiles of 16 (the whole half window of npts = 600, one wave per SIMD), 1 (default) = 10 tiles
- * (two chunks, two waves per SIMD), 2 = 7 tiles (three chunks); choose before sizing/building Tsym. */
-int pta_set_idft_variant(int variant);
-int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int64_t *rot_doubles);
+ * come from pta_gwb_twiddle_sym_size.  `variant` selects the column tiling of a workgroup - 0 = 19 tiles of 16 (the
+ * whole half window of npts = 600, one wave per SIMD), 1 (recommended) = 10 tiles (two chunks, two waves per SIMD),
+ * 2 = 7 tiles (three chunks) - and, since the Tsym layout depends on it, must be the same in all three calls.   */
+int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int variant, int64_t *rot_doubles);
 int pta_gwb_twiddle_sym(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *Tsym, double *rot,
-                        void *stream);
+                        int variant, void *stream);
 int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot, int npts,
-                     double *G0, int64_t ldg, void *stream);
+                     double *G0, int64_t ldg, int variant, int rng_fast, void *stream);
 
 /* The same stage as a chirp-z (Bluestein) transform, the default of the batched engine whenever
  * (Nf-2) + npts - 2 < 4096 (pta_gwb_czt_fits): x_j = (2/(n dt)) Re(W^{j^2/2} sum_k (sqrtC_k w_k W^{k^2/2}) W^{-(j-k)^2/2}),
@@ -173,17 +175,18 @@ int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const dou
  * pta_gwb_czt: w == NULL draws on chip (stream (GWB, a), pair k, like pta_gwb_idft_rng), else w[R*P x ldw]
  * interleaved (re, im) rows as in pta_gwb_idft (ldw = 0: one row of draws shared by all rows - timing probe).  */
 int pta_gwb_czt_fits(int Nf, int npts, int i0);
-int pta_set_czt_variant(int variant); /* 0 (default): six LDS exchanges, draws / product / output in registers, computed twiddles;
-                                          1: every stage through LDS with table twiddles (cross-check); 10+f: ladder step f */
+/* pta_gwb_czt `variant`: 0 (default): six LDS exchanges, draws / product / output in registers, computed twiddles;
+ *                        1: every stage through LDS with table twiddles (cross-check); 10+f: ladder step f              */
 int pta_gwb_czt_setup(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *pre, double *FB, double *tw,
                       double *post, void *stream);
 int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
                 const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
-                void *stream);
+                int variant, int rng_fast, void *stream);
 
 /* G[r,a,:] = sum_b Mchol[a,b] G0[r,b,:]  (the M@w of red_noise.py:268, applied after the DFT). */
-int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream);
-int pta_set_mix_variant(int variant); /* 0 (default): LDS-resident Mchol kernel when P <= 80; 1: always the generic batched GEMM */
+/* variant 0 (default): LDS-resident Mchol kernel when P <= 80, generic batched MFMA GEMM otherwise; 1: always the generic
+ * MFMA GEMM; 2: the generic VALU reference GEMM (cross-check)                                                       */
+int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, int variant, void *stream);
 
 /* jlo[i] = last j with ut[j] <= toa_s[i], clamped to [0, npts-2] (numpy.interp's bracket, which
  * scipy.interpolate.interp1d(kind="linear") delegates to; red_noise.py:286-287).           */
@@ -251,15 +254,15 @@ typedef struct {
   const int32_t *epoch_of;    /* [n_toa] epoch index inside the pulsar */
   const double *ecorr_toa;    /* [n_toa] ecorr of the TOA's epoch (0 = none) */
   const double *det;          /* [n_toa] realisation-independent deterministic delay (e.g. CGW) */
+  int32_t rng_fast;           /* Gaussian transform of the on-chip draws (see "RNG" above); 0 = fp64 (default) */
+  int32_t synth_variant;      /* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs
+                                 per workgroup), workgroups dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same
+                                 kernel in plain linear workgroup order (A/B); 4 / 6 / 8 = all-VALU kernel compiled for that many
+                                 waves per SIMD (kept for cross-checks) */
 } pta_engine_plan;
 
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
-int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, void *stream);
-
-/* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs per workgroup), workgroups
- * dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same kernel in plain linear workgroup order (A/B);
- * 4 / 6 / 8 = all-VALU kernel compiled for that many waves per SIMD (kept for cross-checks)     */
-int pta_set_synth_variant(int min_waves_per_simd);
+int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, int rng_fast, void *stream);
 
 int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
                      void *stream);
@@ -274,12 +277,14 @@ typedef struct {
   int32_t gw_nf;              /* Nf of the GWB frequency grid */
   int32_t gw_i0;              /* crop offset (10, red_noise.py:285) */
   int32_t use_czt;            /* 1: chirp-z tables below; 0: Tsym / rot of the DFT-GEMM form */
-  int32_t reserved;
+  int32_t czt_variant;        /* `variant` of pta_gwb_czt (0 = default) */
   const double *czt_pre, *czt_FB, *czt_tw, *czt_post; /* from pta_gwb_czt_setup */
   const double *Tsym, *rot;   /* from pta_gwb_twiddle_sym */
   double *ws_coef;            /* [R x n_psr x rn_k] */
   double *ws_G0;              /* [R x n_psr x gw_npts] per-pulsar grid series */
   double *ws_G;               /* [R x n_psr x gw_npts] mixed grid series */
+  int32_t idft_variant;       /* `variant` Tsym was built with (pta_gwb_twiddle_sym) */
+  int32_t mix_variant;        /* `variant` of pta_gwb_mix (0 = default) */
 } pta_engine_tables;
 
 int pta_engine_generate(const pta_engine_plan *plan_host, const pta_engine_tables *tables_host, uint64_t seed, uint64_t r0, int R,
@@ -300,7 +305,7 @@ int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const doubl
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or
  * pta_rng_fill_normal(stream (TD, pulsar)) in throughput mode.                              */
 int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld_z, int R, double *out, int64_t ld_out,
-                int accumulate, void *stream);
+                int accumulate, int algo, void *stream);   /* algo: 1 = MFMA GEMM, 0 = VALU reference GEMM */
 
 /* Throughput form of the same draw: Z is never materialised - every lane GENERATES its MFMA A operand in registers
  * (stream kind PTA_STREAM_TD / PTA_STREAM_TDGW, deviate j of row m = pair j >> 1, branch j & 1), so one launch covers all
@@ -351,7 +356,7 @@ int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, in
 /* Measure the roofline denominators on the device the library runs on (bench.py):
  * kind 0: fp64 MFMA (v_mfma_f64_16x16x4_f64) TFLOP/s, 1: fp64 FMA TFLOP/s,
  * 2: HBM write GB/s over `bytes`, 3: HBM copy GB/s, 4: Philox+Box-Muller G normals/s.      */
-int pta_microbench(int kind, int64_t bytes, int iters, double *result_host);
+int pta_microbench(int kind, int64_t bytes, int iters, int option, double *result_host);   /* option: rng_fast of kind 4 */
 
 /* self-test of the fp64 MFMA lane layout used by the GEMM kernels: returns 0 when a 16x16x4
  * product with asymmetric operands matches the scalar result on the device.                */

@@ -37,16 +37,16 @@ class EnginePlan(ctypes.Structure):
         ("tile_psr", _P), ("tile_start", _P), ("tile_count", _P), ("tile_ep0", _P), ("tile_epn", _P),
         ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
         ("gw_jlo", _P), ("gw_w", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
-        ("ecorr_toa", _P), ("det", _P),
+        ("ecorr_toa", _P), ("det", _P), ("rng_fast", c_int32), ("synth_variant", c_int32),
     ]
 
 
 class EngineTables(ctypes.Structure):
     """pta_engine_tables (include/pta_replicator_amd.h)."""
     _fields_ = [
-        ("rn_amp", _P), ("Mchol", _P), ("gw_nf", c_int32), ("gw_i0", c_int32), ("use_czt", c_int32), ("reserved", c_int32),
+        ("rn_amp", _P), ("Mchol", _P), ("gw_nf", c_int32), ("gw_i0", c_int32), ("use_czt", c_int32), ("czt_variant", c_int32),
         ("czt_pre", _P), ("czt_FB", _P), ("czt_tw", _P), ("czt_post", _P), ("Tsym", _P), ("rot", _P),
-        ("ws_coef", _P), ("ws_G0", _P), ("ws_G", _P),
+        ("ws_coef", _P), ("ws_G0", _P), ("ws_G", _P), ("idft_variant", c_int32), ("mix_variant", c_int32),
     ]
 
 
@@ -64,9 +64,8 @@ _SIGNATURES = {
     "pta_abi_version": (c_int, []),
     "pta_last_error": (c_char_p, []),
     "pta_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
-    "pta_set_rng_math": (c_int, [c_int]),
     "pta_rng_philox_raw": (c_int, [_P, _P, c_int, _P, _P]),
-    "pta_rng_fill_normal": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, _P, _P, c_int64, _P]),
+    "pta_rng_fill_normal": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, _P, _P, c_int64, c_int, _P]),
     "pta_rn_basis": (c_int, [_P, c_int, c_double, _P, _P, c_int, c_int, _P, c_int64, _P]),
     "pta_rn_synth": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_wn": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
@@ -77,42 +76,37 @@ _SIGNATURES = {
     "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_potrf_batched": (c_int, [_P, c_int, c_int, _P, _P]),
     "pta_potrf_batched_ex": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P]),
-    "pta_set_gemm_algo": (c_int, [c_int]),
     "pta_gwb_twiddle": (c_int, [_P, c_int, c_int, c_int, c_double, _P, c_int64, _P]),
     "pta_gwb_idft": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
-    "pta_set_idft_variant": (c_int, [c_int]),
-    "pta_gwb_twiddle_sym_size": (c_int64, [c_int, c_int, POINTER(c_int64)]),
-    "pta_gwb_twiddle_sym": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P]),
-    "pta_gwb_idft_rng": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, c_int, _P, c_int64, _P]),
-    "pta_set_czt_variant": (c_int, [c_int]),
-    "pta_set_mix_variant": (c_int, [c_int]),
+    "pta_gwb_twiddle_sym_size": (c_int64, [c_int, c_int, c_int, POINTER(c_int64)]),
+    "pta_gwb_twiddle_sym": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, c_int, _P]),
+    "pta_gwb_idft_rng": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, c_int, _P, c_int64, c_int, c_int, _P]),
     "pta_gwb_czt_fits": (c_int, [c_int, c_int, c_int]),
     "pta_gwb_czt_setup": (c_int, [_P, c_int, c_int, c_int, c_double, _P, _P, _P, _P, _P]),
-    "pta_gwb_czt": (c_int, [c_uint64, c_uint64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
-    "pta_gwb_mix": (c_int, [_P, c_int, _P, c_int, c_int, c_int64, _P, _P]),
+    "pta_gwb_czt": (c_int, [c_uint64, c_uint64, _P, c_int64, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, c_int, c_int, _P]),
+    "pta_gwb_mix": (c_int, [_P, c_int, _P, c_int, c_int, c_int64, _P, c_int, _P]),
     "pta_gwb_bracket": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "pta_gwb_weights": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "pta_gwb_interp": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_double, _P, c_int64, c_int, _P]),
     "pta_cgw": (c_int, [_P, c_int, _P, _P, c_int, _P]),
     "pta_cw_catalog_workspace": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     "pta_cw_catalog": (c_int, [_P, c_int, _P, c_int, _P, _P, c_double, c_int, c_double, c_int, c_int, c_double, _P, _P, _P, c_int, _P]),
-    "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, _P]),
-    "pta_set_synth_variant": (c_int, [c_int]),
+    "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pta_engine_generate": (c_int, [POINTER(EnginePlan), POINTER(EngineTables), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
-    "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, c_int, _P]),
     "pta_td_trmm_rng": (c_int, [POINTER(TdPlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_double, _P, c_int64, c_int64, _P, c_int64, c_double, _P, c_int64,
                           c_int, c_int, c_int64, c_int64, c_int64, c_int, _P]),
-    "pta_microbench": (c_int, [c_int, c_int64, c_int, POINTER(c_double)]),
+    "pta_microbench": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_double)]),
     "pta_selftest_mfma_f64": (c_int, [POINTER(c_double)]),
 }
 
 ENGINE_TILE = 256   # PTA_ENGINE_TILE
 ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
 TD_STRIP = 256      # PTA_TD_STRIP
-POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION = 1, 2, 4
+POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION, POTRF_VALU = 1, 2, 4, 8
 
 EXPORTS = tuple(_SIGNATURES)
 
@@ -121,7 +115,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.pta_abi_version() != 1:
+if lib.pta_abi_version() != 2:
     raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
 
 

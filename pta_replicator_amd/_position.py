@@ -48,11 +48,15 @@ def ecliptic_to_equatorial(elong_deg, elat_deg, name):
     return float(ra), float(dec)
 
 
-def ra_dec(psr):
-    """(ra, dec) [rad] with the reference's branch order (its `"RAJ" and "DECJ" in loc` tests DECJ only)."""
+def ra_dec(psr, default=None):
+    """(ra, dec) [rad] with the reference's branch order (its `"RAJ" and "DECJ" in loc` tests DECJ only).  A loc with
+    neither DECJ nor ELAT: add_gwb silently leaves the pulsar at (0, 0) (red_noise.py:203-221: no else branch), which callers
+    on that path request with default=(0.0, 0.0); add_cgw fails on it (deterministic.py:76-91), as this does without a default."""
     loc = psr.loc
     if "DECJ" in loc:
         return float(loc["RAJ"] * np.pi / 12.0), float(loc["DECJ"] * np.pi / 180.0)
     if "ELAT" in loc:
         return ecliptic_to_equatorial(loc["ELONG"], loc["ELAT"], psr.name)
+    if default is not None:
+        return default
     raise AttributeError("No pulsar location information (RAJ/DECJ or ELONG/ELAT) in psr.loc.")

@@ -41,5 +41,3 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int algo, hipStream_t stream);
 
-// process-wide Gaussian-transform mode (pta_set_rng_math): 0 = fp64 < 1 ulp (default), 1 = hardware fp32 transcendentals
-int pta_get_rng_fast();

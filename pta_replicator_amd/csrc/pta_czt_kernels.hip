@@ -225,16 +225,10 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
   }
 }
 
-static int g_czt_variant = 0;  // 0 = fully fused kernel (default), 1 = plain cross-check (FUSE = 0), 10 + FUSE = any ladder step
-extern "C" int pta_set_czt_variant(int v) {
-  g_czt_variant = v;
-  return PTA_OK;
-}
-
 // w == NULL: draws generated on chip (throughput mode); else w[M x ldw] interleaved (re, im) rows (replay mode)
 extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
                            const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
-                           void *stream) {
+                           int variant, int rng_fast, void *stream) {
   PTA_REQUIRE(pre && FB && tw && post && G0, PTA_E_ARG, "pta_gwb_czt: NULL argument");
   PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && npts > 0 && ldg >= npts, PTA_E_ARG, "pta_gwb_czt: R=%d P=%d npts=%d", R, P, npts);
   PTA_REQUIRE(czt_fits(Nf, npts, i0), PTA_E_ARG, "pta_gwb_czt: Nf=%d npts=%d does not fit one 4096-point convolution", Nf, npts);
@@ -242,8 +236,9 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
   int64_t M64 = (int64_t)R * P;
   PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_czt: R*P too large");
   const int M = (int)M64;
-  const int fastm = pta_get_rng_fast();
-  const int fuse = g_czt_variant == 0 ? 15 : (g_czt_variant == 1 ? 0 : g_czt_variant - 10);
+  // variant: 0 = fully fused kernel (default), 1 = plain cross-check (FUSE = 0), 10 + FUSE = any ladder step
+  const int fastm = rng_fast ? 1 : 0;
+  const int fuse = variant == 0 ? 15 : (variant == 1 ? 0 : variant - 10);
 #define PTA_CZT_X(RNGV, FASTV, FUSEV)                                                                                                  \
   hipLaunchKernelGGL((k_gwb_czt<RNGV, FASTV, FUSEV>), dim3(M), dim3(PTA_FFT_THREADS), 0, pta_stream(stream), seed, r0, w, ldw, M, P, \
                      Nf, npts, i0, pre, FB, tw, post, G0, ldg)
@@ -261,7 +256,7 @@ extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t 
     case 3: PTA_CZT_XF(3); break;
     case 7: PTA_CZT_XF(7); break;
     case 8: PTA_CZT_XF(8); break;
-    default: pta_set_error("pta_gwb_czt: unknown variant %d", g_czt_variant); return PTA_E_ARG;
+    default: pta_set_error("pta_gwb_czt: unknown variant %d", variant); return PTA_E_ARG;
   }
 #undef PTA_CZT_XF
 #undef PTA_CZT_X

@@ -24,13 +24,13 @@ __global__ void k_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K
   coef[o + 1] = amp[(int64_t)a * K + 2 * p + 1] * z1;
 }
 
-extern "C" int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef,
+extern "C" int pta_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *amp, double *coef, int rng_fast,
                                   void *stream) {
   PTA_REQUIRE(amp && coef, PTA_E_ARG, "pta_engine_rn_coef: NULL argument");
   PTA_REQUIRE(R > 0 && P > 0 && K > 0 && (K % 2) == 0, PTA_E_ARG, "pta_engine_rn_coef: R=%d P=%d K=%d (K must be even)", R, P, K);
   int64_t total = (int64_t)R * P * (K / 2);
   PTA_REQUIRE(total < (1LL << 31), PTA_E_ARG, "pta_engine_rn_coef: problem too large");
-  hipLaunchKernelGGL(k_engine_rn_coef, dim3(pta_cdiv(total, 256)), dim3(256), 0, pta_stream(stream), seed, r0, R, P, K, amp, coef, pta_get_rng_fast());
+  hipLaunchKernelGGL(k_engine_rn_coef, dim3(pta_cdiv(total, 256)), dim3(256), 0, pta_stream(stream), seed, r0, R, P, K, amp, coef, rng_fast ? 1 : 0);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
@@ -253,12 +253,6 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
   }
 }
 
-static int g_synth_minw = 0;  // 0 = MFMA variant (default); 4 / 6 / 8 = VALU variant compiled for that many waves per SIMD
-extern "C" int pta_set_synth_variant(int minw) {
-  g_synth_minw = minw;
-  return PTA_OK;
-}
-
 extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
                                 void *stream) {
   PTA_REQUIRE(plan_host && out, PTA_E_ARG, "pta_engine_synth: NULL argument");
@@ -272,12 +266,13 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
               "pta_engine_synth: GWB inputs missing");
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
-  PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed one launch", p.n_tiles);
-  if (g_synth_minw == 0 || g_synth_minw == 1) {  // 1: same kernel, plain linear workgroup order (A/B of the XCD mapping)
-    const int xcd = g_synth_minw == 0 ? 1 : 0;
+  const int variant = p.synth_variant;  // 0 = MFMA kernel (default); 1 = same, linear workgroup order; 4 / 6 / 8 = all-VALU kernel
+  const int rng_fast = p.rng_fast ? 1 : 0;
+  if (variant == 0 || variant == 1) {  // 1: same kernel, plain linear workgroup order (A/B of the XCD mapping)
+    const int xcd = variant == 0 ? 1 : 0;
     const int64_t total = (int64_t)pta_cdiv(R, ENG_MR) * p.n_tiles, nwg = ((total + 7) >> 3) << 3;
     PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_engine_synth: %lld workgroups exceed one launch", (long long)nwg);
-    if (pta_get_rng_fast())
+    if (rng_fast)
       hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R, out,
                          ld_out, xcd);
     else
@@ -286,25 +281,27 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
     PTA_LAUNCH_CHECK();
     return PTA_OK;
   }
+  PTA_REQUIRE(p.n_tiles <= 65535, PTA_E_ARG, "pta_engine_synth: %d tiles exceed the 2-D launch of the all-VALU kernel", p.n_tiles);
   dim3 g(pta_cdiv(R, ENG_RB), p.n_tiles), b(PTA_ENGINE_TILE);
   // register budget per lane (waves per SIMD the compiler must allow): the kernel alternates long Box-Muller chains
   // with a load-fed FMA loop, so occupancy matters more than keeping all eight chains' temporaries in registers
-  if (g_synth_minw >= 8)
-    hipLaunchKernelGGL(k_engine_synth<8>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
-  else if (g_synth_minw >= 6)
-    hipLaunchKernelGGL(k_engine_synth<6>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
+  if (variant >= 8)
+    hipLaunchKernelGGL(k_engine_synth<8>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, rng_fast);
+  else if (variant >= 6)
+    hipLaunchKernelGGL(k_engine_synth<6>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, rng_fast);
   else
-    hipLaunchKernelGGL(k_engine_synth<4>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, pta_get_rng_fast());
+    hipLaunchKernelGGL(k_engine_synth<4>, g, b, 0, pta_stream(stream), p, seed, r0, R, out, ld_out, rng_fast);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
 
 extern "C" int pta_gwb_czt(uint64_t seed, uint64_t r0, const double *w, int64_t ldw, int R, int P, int Nf, int npts, int i0,
                            const double *pre, const double *FB, const double *tw, const double *post, double *G0, int64_t ldg,
-                           void *stream);
+                           int variant, int rng_fast, void *stream);
 extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot, int npts,
-                                double *G0, int64_t ldg, void *stream);
-extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream);
+                                double *G0, int64_t ldg, int variant, int rng_fast, void *stream);
+extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, int variant,
+                           void *stream);
 
 extern "C" int pta_engine_generate(const pta_engine_plan *plan_host, const pta_engine_tables *tables_host, uint64_t seed, uint64_t r0,
                                    int R, double *out, int64_t ld_out, void *stream) {
@@ -314,7 +311,7 @@ extern "C" int pta_engine_generate(const pta_engine_plan *plan_host, const pta_e
   int rc;
   if (p.rn_k > 0) {
     PTA_REQUIRE(tb.rn_amp && tb.ws_coef, PTA_E_ARG, "pta_engine_generate: red-noise amplitudes / workspace missing");
-    rc = pta_engine_rn_coef(seed, r0, R, p.n_psr, p.rn_k, tb.rn_amp, tb.ws_coef, stream);
+    rc = pta_engine_rn_coef(seed, r0, R, p.n_psr, p.rn_k, tb.rn_amp, tb.ws_coef, p.rng_fast, stream);
     if (rc != PTA_OK) return rc;
     p.rn_coef = tb.ws_coef;
   }
@@ -323,13 +320,13 @@ extern "C" int pta_engine_generate(const pta_engine_plan *plan_host, const pta_e
     if (tb.use_czt) {
       PTA_REQUIRE(tb.czt_pre && tb.czt_FB && tb.czt_tw && tb.czt_post, PTA_E_ARG, "pta_engine_generate: chirp-z tables missing");
       rc = pta_gwb_czt(seed, r0, nullptr, 0, R, p.n_psr, tb.gw_nf, p.gw_npts, tb.gw_i0, tb.czt_pre, tb.czt_FB, tb.czt_tw, tb.czt_post,
-                       tb.ws_G0, p.gw_npts, stream);
+                       tb.ws_G0, p.gw_npts, tb.czt_variant, p.rng_fast, stream);
     } else {
       PTA_REQUIRE(tb.Tsym && tb.rot, PTA_E_ARG, "pta_engine_generate: DFT-GEMM tables missing");
-      rc = pta_gwb_idft_rng(seed, r0, R, p.n_psr, tb.gw_nf, tb.Tsym, tb.rot, p.gw_npts, tb.ws_G0, p.gw_npts, stream);
+      rc = pta_gwb_idft_rng(seed, r0, R, p.n_psr, tb.gw_nf, tb.Tsym, tb.rot, p.gw_npts, tb.ws_G0, p.gw_npts, tb.idft_variant, p.rng_fast, stream);
     }
     if (rc != PTA_OK) return rc;
-    rc = pta_gwb_mix(tb.Mchol, p.n_psr, tb.ws_G0, R, p.gw_npts, p.gw_npts, tb.ws_G, stream);
+    rc = pta_gwb_mix(tb.Mchol, p.n_psr, tb.ws_G0, R, p.gw_npts, p.gw_npts, tb.ws_G, tb.mix_variant, stream);
     if (rc != PTA_OK) return rc;
     p.gw_G = tb.ws_G;
   }

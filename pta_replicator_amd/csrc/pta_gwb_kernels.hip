@@ -12,7 +12,6 @@
 #include "pta_mfma.h"
 #include "pta_rng.h"
 
-int pta_get_gemm_algo();
 
 // T0[k-1][jj] =  amp_k cos(2 pi j k / n),  T1[k-1][jj] = -amp_k sin(2 pi j k / n),  j = i0 + jj,
 // amp_k = 2 sqrtC[k] / (n dt): the factor 2 is the Hermitian partner bin, 1/n numpy's ifft norm,
@@ -201,18 +200,14 @@ __global__ __launch_bounds__(256, MINW) void k_gwb_idft_sym_rng(uint64_t seed, u
   }
 }
 
-static int g_idft_variant = 1;  // 0: NT = 19 (whole half window per workgroup, 1 wave/SIMD), 1: NT = 10 (2 chunks, 2 waves/SIMD), 2: NT = 7 (3 chunks)
-extern "C" int pta_set_idft_variant(int v) {
-  g_idft_variant = v;
-  return PTA_OK;
-}
-
-static int sym_nt() { return g_idft_variant == 1 ? 10 : (g_idft_variant == 2 ? 7 : 19); }
+// column tiling of a workgroup: variant 0: NT = 19 (whole half window per workgroup, 1 wave/SIMD), 1 (recommended): NT = 10
+// (2 chunks, 2 waves/SIMD), 2: NT = 7 (3 chunks).  The Tsym layout depends on it, so the same value goes to all three calls.
+static int sym_nt(int variant) { return variant == 1 ? 10 : (variant == 2 ? 7 : 19); }
 static int sym_pitch(int nt) { return (nt % 2) ? nt * 16 : nt * 16 + 16; }
 static int sym_slab_pad(int nt) { return ((8 * sym_pitch(nt) / 2 + 255) / 256) * 512; }
 
-extern "C" int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int64_t *rot_doubles) {
-  const int nt = sym_nt();
+extern "C" int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int variant, int64_t *rot_doubles) {
+  const int nt = sym_nt(variant);
   const int nstep = (Nf - 2 + 3) >> 2;
   const int half = (npts + 1) >> 1;
   const int nchunk = (half + nt * 16 - 1) / (nt * 16);
@@ -221,10 +216,10 @@ extern "C" int64_t pta_gwb_twiddle_sym_size(int Nf, int npts, int64_t *rot_doubl
 }
 
 extern "C" int pta_gwb_twiddle_sym(const double *sqrtC, int Nf, int npts, int i0, double inv_dt, double *Tsym, double *rot,
-                                   void *stream) {
+                                   int variant, void *stream) {
   PTA_REQUIRE(sqrtC && Tsym && rot, PTA_E_ARG, "pta_gwb_twiddle_sym: NULL argument");
   PTA_REQUIRE(Nf >= 3 && npts > 0 && i0 >= 0, PTA_E_ARG, "pta_gwb_twiddle_sym: Nf=%d npts=%d", Nf, npts);
-  const int nt = sym_nt();
+  const int nt = sym_nt(variant);
   const int nstep = (Nf - 2 + 3) >> 2;
   const int half = (npts + 1) >> 1;
   const int nchunk = (half + nt * 16 - 1) / (nt * 16);
@@ -241,14 +236,15 @@ extern "C" int pta_gwb_twiddle_sym(const double *sqrtC, int Nf, int npts, int i0
 }
 
 extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf, const double *Tsym, const double *rot,
-                                int npts, double *G0, int64_t ldg, void *stream) {
+                                int npts, double *G0, int64_t ldg, int variant, int rng_fast, void *stream) {
   PTA_REQUIRE(Tsym && rot && G0, PTA_E_ARG, "pta_gwb_idft_rng: NULL argument");
   PTA_REQUIRE(R > 0 && P > 0 && P < (1 << 24) && Nf >= 3 && npts > 0 && ldg >= npts, PTA_E_ARG,
               "pta_gwb_idft_rng: R=%d P=%d Nf=%d npts=%d", R, P, Nf, npts);
   int64_t M64 = (int64_t)R * P;
   PTA_REQUIRE(M64 < (1LL << 31), PTA_E_ARG, "pta_gwb_idft_rng: R*P too large");
   const int M = (int)M64;
-  const int nt = sym_nt();
+  const int nt = sym_nt(variant);
+  rng_fast = rng_fast ? 1 : 0;
   const int half = (npts + 1) >> 1;
   const int nchunk = (half + nt * 16 - 1) / (nt * 16);
   const size_t shmem = 2 * (size_t)sym_slab_pad(nt) * sizeof(double);
@@ -256,15 +252,15 @@ extern "C" int pta_gwb_idft_rng(uint64_t seed, uint64_t r0, int R, int P, int Nf
   if (nt == 19) {
     auto kern = k_gwb_idft_sym_rng<19, 1>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, rng_fast);
   } else if (nt == 10) {
     auto kern = k_gwb_idft_sym_rng<10, 2>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, rng_fast);
   } else {
     auto kern = k_gwb_idft_sym_rng<7, 2>;
     PTA_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, pta_get_rng_fast());
+    hipLaunchKernelGGL(kern, g, dim3(256), shmem, pta_stream(stream), seed, r0, M, P, Nf, Tsym, rot, npts, G0, ldg, rng_fast);
   }
   PTA_LAUNCH_CHECK();
   return PTA_OK;
@@ -325,17 +321,14 @@ __global__ __launch_bounds__(256) void k_gwb_mix_small(const double *__restrict_
   }
 }
 
-static int g_mix_variant = 0;  // 0 = specialised kernel when P <= 80, 1 = always the generic batched GEMM
-extern "C" int pta_set_mix_variant(int v) {
-  g_mix_variant = v;
-  return PTA_OK;
-}
-
-extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, void *stream) {
+// variant: 0 = specialised kernel when P <= 80 (else the generic batched MFMA GEMM), 1 = always the generic MFMA GEMM,
+// 2 = the generic VALU reference GEMM
+extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, int npts, int64_t ldg, double *G, int variant,
+                           void *stream) {
   PTA_REQUIRE(Mchol && G0 && G, PTA_E_ARG, "pta_gwb_mix: NULL argument");
   PTA_REQUIRE(P > 0 && R > 0 && npts > 0 && ldg >= npts, PTA_E_ARG, "pta_gwb_mix: P=%d R=%d npts=%d", P, R, npts);
   const int64_t sr = (int64_t)P * ldg;
-  if (g_mix_variant == 0 && P <= 80) {
+  if (variant == 0 && P <= 80) {
     const int nta = (P + 15) / 16, kp = (P + 3) & ~3;
     const int rpw = 4;
     const size_t shmem = (size_t)kp * nta * 16 * sizeof(double);
@@ -356,7 +349,7 @@ extern "C" int pta_gwb_mix(const double *Mchol, int P, const double *G0, int R, 
   for (int rb = 0; rb < R; rb += 32768) {
     int rc_ = (R - rb < 32768) ? (R - rb) : 32768;
     int rc = pta_dgemm_launch(0, P, npts, P, 1.0, Mchol, P, 1, G0 + rb * sr, ldg, 0.0, G + rb * sr, ldg, 0, rc_, 0, sr, sr,
-                              pta_get_gemm_algo(), pta_stream(stream));
+                              variant == 2 ? 0 : 1, pta_stream(stream));
     if (rc != PTA_OK) return rc;
   }
   return PTA_OK;

@@ -15,13 +15,6 @@ void pta_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 
-static int g_rng_fast = 0;
-extern "C" int pta_set_rng_math(int fast) {
-  g_rng_fast = fast ? 1 : 0;
-  return PTA_OK;
-}
-int pta_get_rng_fast() { return g_rng_fast; }
-
 extern "C" int pta_abi_version(void) { return PTA_ABI_VERSION; }
 extern "C" const char *pta_last_error(void) { return g_err; }
 

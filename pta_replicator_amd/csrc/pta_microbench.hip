@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_mb_rng(double *out, int iters, int fast
   if (s == 123.456) out[0] = s;
 }
 
-extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result_host) {
+extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, double *result_host) {
   PTA_REQUIRE(result_host && iters > 0, PTA_E_ARG, "pta_microbench: bad argument");
   int dev = 0;
   PTA_HIP(hipGetDevice(&dev));
@@ -99,7 +99,7 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, double *result
           work = 2.0 * (double)nbytes * reps;
           break;
         case 4:
-          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, pta_get_rng_fast());
+          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, option ? 1 : 0);
           work = (double)cus * bpc * 256 * iters * 2.0 * reps;  // normals
           break;
         default:

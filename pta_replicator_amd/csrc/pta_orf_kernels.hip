@@ -230,12 +230,6 @@ __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t
   if (c < n && c > r) A[(int64_t)blockIdx.z * sA + (int64_t)r * lda + c] = 0.0;
 }
 
-static int g_gemm_algo = 1;
-extern "C" int pta_set_gemm_algo(int algo) {
-  g_gemm_algo = algo ? 1 : 0;
-  return PTA_OK;
-}
-int pta_get_gemm_algo() { return g_gemm_algo; }
 
 // Side stream + events of the look-ahead schedule below, created on first use for the calling thread's current device.
 struct pta_potrf_ctx {
@@ -278,6 +272,7 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
   PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
               (long long)lda, (long long)strideA);
   hipStream_t s = pta_stream(stream);
+  const int g_gemm_algo = (flags & PTA_POTRF_VALU) ? 0 : 1;  // VALU reference GEMM + substitution panel solve (cross-check)
   const int NBO = 4 * CH_NB;
   const bool look = !(flags & PTA_POTRF_NO_LOOKAHEAD) && g_gemm_algo && n > 2 * NBO;
   pta_potrf_ctx *cx = nullptr;

@@ -39,14 +39,14 @@ __global__ void k_fill_normal(uint64_t seed, uint64_t r0, uint32_t stream_id, in
 }
 
 extern "C" int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t stream_id, int npairs, int interleave,
-                                   double *z0, double *z1, int64_t ld, void *stream) {
+                                   double *z0, double *z1, int64_t ld, int rng_fast, void *stream) {
   PTA_REQUIRE(z0 && (interleave || z1), PTA_E_ARG, "pta_rng_fill_normal: NULL output");
   PTA_REQUIRE(R > 0 && npairs > 0, PTA_E_ARG, "pta_rng_fill_normal: R=%d npairs=%d", R, npairs);
   PTA_REQUIRE(ld >= (interleave ? 2 * (int64_t)npairs : (int64_t)npairs), PTA_E_ARG, "pta_rng_fill_normal: ld too small");
   PTA_REQUIRE(!interleave || (ld % 2 == 0 && ((uintptr_t)z0 % 16) == 0), PTA_E_ARG,
               "pta_rng_fill_normal: interleaved output needs even ld and 16-byte alignment");
   hipLaunchKernelGGL(k_fill_normal, dim3(pta_cdiv(npairs, 256), R), dim3(256), 0, pta_stream(stream), seed, r0, stream_id,
-                     npairs, interleave, z0, z1, ld, pta_get_rng_fast());
+                     npairs, interleave, z0, z1, ld, rng_fast ? 1 : 0);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

@@ -88,14 +88,12 @@ extern "C" int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, 
   return PTA_OK;
 }
 
-int pta_get_gemm_algo();
-
 // out[r, i] (+)= sum_j z[r, j] L[i, j]  =  (Z . L^T)[r, i]; L's strict upper triangle is zero.
 extern "C" int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld_z, int R, double *out, int64_t ld_out,
-                           int accumulate, void *stream) {
+                           int accumulate, int algo, void *stream) {
   PTA_REQUIRE(L && z && out, PTA_E_ARG, "pta_td_trmm: NULL argument");
   PTA_REQUIRE(N > 0 && R > 0 && ldl >= N && ld_z >= N && ld_out >= N, PTA_E_ARG, "pta_td_trmm: N=%d R=%d", N, R);
-  return pta_dgemm_launch(1, R, N, N, 1.0, z, ld_z, 1, L, ldl, accumulate ? 1.0 : 0.0, out, ld_out, 0, 1, 0, 0, 0, pta_get_gemm_algo(),
+  return pta_dgemm_launch(1, R, N, N, 1.0, z, ld_z, 1, L, ldl, accumulate ? 1.0 : 0.0, out, ld_out, 0, 1, 0, 0, 0, algo ? 1 : 0,
                           pta_stream(stream));
 }
 
@@ -116,6 +114,7 @@ extern "C" int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z,
 #define TDS_K 16
 #define TDS_LD 260
 #define TDS_NT (TDS_N / 16)
+#define TDS_MANY_ITEMS 64  // from this many strips on, whole strips are dealt to the XCDs (see the work item order below)
 
 template <bool FAST>
 __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t seed, uint64_t r0, int M, double *__restrict__ out,
@@ -125,12 +124,21 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   // work item order: items are sorted by decreasing K extent (host); consecutive workgroups go to the 8 XCDs round-robin, so
   // XCD x takes items x, x + 8, ... (each XCD gets the same mix of long and short strips) and walks the Z-row groups of one
   // item back to back: the strip of L is fetched into ONE L2 and re-read there by the other row groups.
+  // With FEW items (the single grid factor of the GWB: 3 strips) that scheme would leave XCDs idle; then every XCD works on
+  // every item and takes the Z-row groups mg = xcd (mod 8) instead - the factor is small enough to sit in all eight L2s.
   const int nmg = (M + TDS_M - 1) / TDS_M;
   const int lin = blockIdx.x;
   const int seq = lin >> 3;
-  const int item = (seq / nmg) * 8 + (lin & 7);
-  if (item >= pl.n_items) return;
-  const int mg = seq % nmg;
+  int item, mg;
+  if (pl.n_items >= TDS_MANY_ITEMS) {
+    item = (seq / nmg) * 8 + (lin & 7);
+    mg = seq % nmg;
+  } else {
+    const int nmg8 = (nmg + 7) >> 3;
+    item = seq / nmg8;
+    mg = (seq % nmg8) * 8 + (lin & 7);
+  }
+  if (item >= pl.n_items || mg >= nmg) return;
   const int blk = pl.item_blk[item];
   const int n0 = pl.item_n0[item];
   const int n = pl.blk_n[blk];
@@ -249,7 +257,7 @@ extern "C" int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint
               "pta_td_trmm_rng: GWB epilogue needs rows_per_real == 1, gw_jlo, gw_w, gw_npts >= 2");
   PTA_REQUIRE(((uintptr_t)p.Lbase % 16) == 0, PTA_E_ARG, "pta_td_trmm_rng: Lbase must be 16-byte aligned");
   const int64_t nmg = pta_cdiv(M, TDS_M);
-  const int64_t nwg = (int64_t)((p.n_items + 7) / 8) * 8 * nmg;
+  const int64_t nwg = p.n_items >= TDS_MANY_ITEMS ? (int64_t)((p.n_items + 7) / 8) * 8 * nmg : (int64_t)p.n_items * ((nmg + 7) / 8) * 8;
   PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_td_trmm_rng: %lld workgroups exceed one launch", (long long)nwg);
   if (p.rng_fast)
     hipLaunchKernelGGL(k_td_trmm_rng<true>, dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);

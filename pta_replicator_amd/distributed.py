@@ -3,9 +3,11 @@ over xGMI on ROCm, "gloo" on CPU for the tests).
 
 There is no exchange step inside the path: every rank owns a contiguous range of the global
 realisation index and draws from the same counter-based stream, so the ensemble is bit-identical for any number
-of GPUs.  The only collective is the final gather of the residual arrays to rank 0 named by BASELINE.json's
-north_star; it is chunked so that rank 0 never needs more than its own slice plus the full result, and can be
-skipped entirely when each rank writes its own shard.
+of GPUs.  The only communication is the final gather of the residual arrays to rank 0 named by BASELINE.json's
+north_star.  Rank 0's ingress (7 xGMI links) bounds it - 39 GB at config 4, >= 37 ms - so
+``generate_gathered`` pipelines it: every rank generates chunk c+1 on its compute stream while chunk c travels, and
+rank 0 receives each chunk STRAIGHT into its rows of the final [total, n_toa] tensor (point-to-point receives into
+row slices: no per-rank staging buffers, no concatenation - rank 0 holds the ensemble once).
 """
 import torch
 import torch.distributed as dist
@@ -22,16 +24,121 @@ def shard_range(total, rank=None, world=None):
     return start, start + base + (1 if rank < rem else 0)
 
 
-def generate_sharded(engine, total, r0=0):
+def rng_mode_consistent(engine):
+    """every rank must run the same Gaussian-transform mode, or realisation r would depend on which rank drew it
+    (the mode is per-engine state: ReplicaEngine.rng_fast).  Raises if the ranks disagree."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return True
+    dev = getattr(engine, "comm_device", None) or (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+    v = int(getattr(engine, "rng_fast", 0))
+    t = torch.tensor([v, -v], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0].item()) != -int(t[1].item()):
+        raise RuntimeError("ranks disagree on the RNG math mode (engine.rng_fast): the ensemble would not be reproducible")
+    return True
+
+
+def generate_sharded(engine, total, r0=0, td=False):
     """this rank's shard of realisations r0 .. r0+total-1 -> (local tensor [R_loc, n_toa], (start, stop))."""
+    rng_mode_consistent(engine)
     start, stop = shard_range(total)
-    return engine.generate(stop - start, r0=r0 + start), (start, stop)
+    gen = engine.generate_td if td else engine.generate
+    return gen(stop - start, r0=r0 + start), (start, stop)
+
+
+class _Side:
+    """a side stream for the communication calls when the tensors live on a GPU; a no-op on CPU (gloo tests)."""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+
+    def after_main(self):
+        """communication issued from now on starts after everything queued on the current (compute) stream."""
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+
+    def __enter__(self):
+        if self.cuda:
+            self._ctx = torch.cuda.stream(self.stream)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.cuda:
+            self._ctx.__exit__(*a)
+
+
+def generate_gathered(engine, total, r0=0, chunk=256, dst=0, td=False, generate=None, n_cols=None, device=None, dtype=torch.float64):
+    """All `total` realisations r0 .. r0+total-1 on rank `dst` as one [total, n_toa] tensor (None on the other ranks),
+    generated shard-wise on every rank and gathered chunk by chunk while the next chunk is being generated.
+
+    `generate(n, r0, out)` defaults to engine.generate / engine.generate_td; passing a callable (plus n_cols / device)
+    lets the CPU tests drive the pipeline without a GPU."""
+    gen = generate or (engine.generate_td if td else engine.generate)
+    n_cols = n_cols if n_cols is not None else engine.n_toa
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        out = torch.empty((total, n_cols), dtype=dtype, device=device)
+        for lo in range(0, total, chunk):
+            n = min(chunk, total - lo)
+            gen(n, r0=r0 + lo, out=out[lo:lo + n])
+        return out
+    if engine is not None:
+        rng_mode_consistent(engine)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(total, r, world) for r in range(world)]
+    start, stop = sizes[rank]
+    rows = stop - start
+    nchunks = max((b - a + chunk - 1) // chunk for a, b in sizes)
+    side = _Side(device)
+    pending = []
+    if rank == dst:
+        result = torch.empty((total, n_cols), dtype=dtype, device=device)
+        for c in range(nchunks):
+            lo = c * chunk
+            ops = []
+            for src, (a, b) in enumerate(sizes):
+                n = min(chunk, (b - a) - lo)
+                if src != dst and n > 0:
+                    ops.append(dist.P2POp(dist.irecv, result[a + lo:a + lo + n], src))
+            if ops:
+                with side:                                   # receives run beside this rank's own generation
+                    pending += dist.batch_isend_irecv(ops)
+            n = min(chunk, rows - lo)
+            if n > 0:
+                gen(n, r0=r0 + start + lo, out=result[start + lo:start + lo + n])
+        for req in pending:
+            req.wait()
+        return result
+    bufs = [torch.empty((min(chunk, max(rows, 1)), n_cols), dtype=dtype, device=device) for _ in range(2)]
+    inflight = [None, None]
+    for c in range(nchunks):
+        lo = c * chunk
+        n = min(chunk, rows - lo)
+        if n <= 0:
+            break
+        b = c & 1
+        if inflight[b] is not None:                          # the buffer's previous chunk must have left before it is refilled
+            for req in inflight[b]:
+                req.wait()
+        gen(n, r0=r0 + start + lo, out=bufs[b][:n])
+        side.after_main()
+        with side:
+            inflight[b] = dist.batch_isend_irecv([dist.P2POp(dist.isend, bufs[b][:n], dst)])
+    for reqs in inflight:
+        for req in reqs or []:
+            req.wait()
+    return None
 
 
 def gather_to_rank0(local, total=None, dst=0):
-    """Gather row-sharded [R_loc, n] tensors to rank `dst` in global row order.  Returns the [total, n] tensor on
-    `dst`, None elsewhere.  Shards may differ in size by one row (shard_range); they are padded for the
-    collective and trimmed after it."""
+    """Gather row-sharded [R_loc, n] tensors (shard_range layout) to rank `dst` in global row order.  Returns the
+    [total, n] tensor on `dst`, None elsewhere.  Point-to-point: `dst` receives every shard directly into its rows of
+    the result, so it holds the ensemble once (plus nothing)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -40,15 +147,17 @@ def gather_to_rank0(local, total=None, dst=0):
         dist.all_reduce(t)
         total = int(t.item())
     sizes = [shard_range(total, r, world) for r in range(world)]
-    rows = max(b - a for a, b in sizes)
     assert local.shape[0] == sizes[rank][1] - sizes[rank][0], "local shard does not match shard_range()"
-    send = local
-    if local.shape[0] != rows:
-        send = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        send[:local.shape[0]] = local
-    send = send.contiguous()
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, bufs, dst=dst)
+    local = local.contiguous()
     if rank != dst:
+        if local.shape[0]:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local, dst)]):
+                req.wait()
         return None
-    return torch.cat([bufs[r][:sizes[r][1] - sizes[r][0]] for r in range(world)], dim=0)
+    result = torch.empty((total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    ops = [dist.P2POp(dist.irecv, result[a:b], src) for src, (a, b) in enumerate(sizes) if src != dst and b > a]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    result[sizes[dst][0]:sizes[dst][1]] = local
+    for req in reqs:
+        req.wait()
+    return result

@@ -62,6 +62,18 @@ class ReplicaEngine(TimeDomainMixin):
         self._prepared = False
         # frequency -> time transform of the GWB in throughput mode: "auto" = chirp-z FFT when it fits, else the MFMA DFT-GEMM
         self.gwb_transform = "auto"
+        # per-engine options, copied into the plan / tables structs of every call (the library has no process-wide switches)
+        self.rng_fast = 0        # 1 = fp32-transcendental Gaussian transform (opt-in; all ranks of a job must agree)
+        self.synth_variant = 0   # pta_engine_plan.synth_variant
+        self.czt_variant = 0     # pta_engine_tables.czt_variant
+        self.mix_variant = 0     # pta_engine_tables.mix_variant
+        self.idft_variant = 1    # column tiling of the DFT-GEMM form; fixed at prepare() (the twiddle layout depends on it)
+        # how the GWB of generate() is drawn: "fourier" (default) = the reference's 2 Nf complex-bin deviates per pulsar through
+        # its frequency-domain synthesis (replayable through the reference algebra, dump_draws / replay); "grid" = npts deviates
+        # per pulsar through the Cholesky factor of the covariance that synthesis implies on the npts-sample grid (SURVEY.md
+        # App. A.1) - same distribution, 10x fewer deviates, the transform becomes an MFMA triangular product
+        self.gwb_mode = "fourier"
+        self.workspace_bytes = 8 << 30   # upper bound of the per-batch workspace of generate() (cap by bytes, not only by count)
 
     # ---------------------------------------------------------------- configuration -------------
     def set_red_noise(self, log10_amplitude, spectral_index, components=30, libstempo_convention=False):
@@ -113,6 +125,7 @@ class ReplicaEngine(TimeDomainMixin):
         dev = dv.require_gpu()
         self._ws = None  # tables of a previous prepare() point at replaced buffers
         self._td_prepared = False  # and so do the dense factors of TD mode
+        self._gw_grid_ready = False
         s = dv.stream_ptr()
         P, N = self.P, self.n_toa
         self.d_psr_of = dv.i32(np.repeat(np.arange(P), self.counts))
@@ -254,12 +267,14 @@ class ReplicaEngine(TimeDomainMixin):
             _lib.call("pta_gwb_twiddle", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_T), self.ldt, s)
             # throughput-mode layout of the same twiddles: half window, slab-major, plus the per-bin rotation
             nrot = ctypes.c_int64(0)
-            nsym = _lib.lib.pta_gwb_twiddle_sym_size(Nf, npts, ctypes.byref(nrot))
+            nsym = _lib.lib.pta_gwb_twiddle_sym_size(Nf, npts, self.idft_variant, ctypes.byref(nrot))
+            self._idft_variant_built = self.idft_variant
             self.d_Tsym, self.d_rot = dv.empty((nsym,)), dv.empty((nrot.value,))
             _lib.call("pta_gwb_twiddle_sym", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]), dv.ptr(self.d_Tsym),
-                      dv.ptr(self.d_rot), s)
+                      dv.ptr(self.d_rot), self.idft_variant, s)
             # chirp-z tables (default frequency -> time transform whenever one 4096-point convolution covers the window)
             self.use_czt = bool(_lib.lib.pta_gwb_czt_fits(Nf, npts, 10)) and self.gwb_transform != "gemm"
+            self.d_czt = None
             if self.use_czt:
                 self.d_czt = [dv.empty((2 * 4096,)), dv.empty((2 * 4096,)), dv.empty((2 * 4096,)), dv.empty((2 * npts,))]
                 _lib.call("pta_gwb_czt_setup", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / grid["dt"]),
@@ -336,13 +351,26 @@ class ReplicaEngine(TimeDomainMixin):
                 ws["G0"] = dv.empty((R, self.P, self.plan.gw_npts))
                 ws["G"] = dv.empty((R, self.P, self.plan.gw_npts))
                 tb.Mchol, tb.ws_G0, tb.ws_G = self.d_M.data_ptr(), ws["G0"].data_ptr(), ws["G"].data_ptr()
-                tb.gw_nf, tb.gw_i0, tb.use_czt = self.grid["Nf"], 10, 1 if self.use_czt else 0
-                if self.use_czt:
+                tb.gw_nf, tb.gw_i0 = self.grid["Nf"], 10
+                if getattr(self, "d_czt", None) is not None:
                     tb.czt_pre, tb.czt_FB, tb.czt_tw, tb.czt_post = (x.data_ptr() for x in self.d_czt)
                 tb.Tsym, tb.rot = self.d_Tsym.data_ptr(), self.d_rot.data_ptr()
+                tb.idft_variant = self._idft_variant_built
             ws["tables"] = tb
             self._ws = ws
+        ws["tables"].czt_variant, ws["tables"].mix_variant = int(self.czt_variant), int(self.mix_variant)
+        if self.plan.gw_npts:
+            if self.use_czt and getattr(self, "d_czt", None) is None:
+                raise ValueError("use_czt was switched on after prepare(): the chirp-z tables were not built")
+            ws["tables"].use_czt = 1 if self.use_czt else 0
+        self.plan.rng_fast, self.plan.synth_variant = int(self.rng_fast), int(self.synth_variant)
         return ws
+
+    def max_batch(self):
+        """realisations per launch sequence: the launch-grid limit of the mix / fused kernels (65536) and the workspace byte
+        budget (coef + G0 + G per realisation: 0.68 MB at 68 pulsars, so 8 GiB hold 12 600 realisations)."""
+        per_real = 8 * self.P * ((self.K if self.plan.rn_k else 0) + 2 * self.plan.gw_npts)
+        return int(max(16, min(65536, self.workspace_bytes // max(per_real, 1))))
 
     def generate(self, R, r0=0, out=None):
         """out[R, n_toa] (device tensor, seconds): realisations r0 .. r0+R-1, every deviate drawn on chip: one call of
@@ -351,12 +379,27 @@ class ReplicaEngine(TimeDomainMixin):
             self.prepare()
         if out is None:
             out = dv.empty((R, self.n_toa))
-        step = 65536                                        # launch-grid limits of the mix / fused kernels; also bounds the workspace
+        step = self.max_batch()
         ws = self.workspace(min(R, step))
+        grid_mode = self.gwb_mode == "grid" and self.plan.gw_npts
+        if grid_mode:
+            self._prepare_gw_grid_factor()
+            self.tdgw_plan.rng_fast = int(self.rng_fast)
+        s = dv.stream_ptr()
         for lo in range(0, R, step):
             n = min(step, R - lo)
-            _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0 + lo, n,
-                      ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)), out.stride(0), dv.stream_ptr())
+            optr = ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0))
+            if not grid_mode:
+                _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0 + lo, n, optr, out.stride(0), s)
+                continue
+            pl = _lib.EnginePlan.from_buffer_copy(self.plan)
+            if pl.rn_k:
+                _lib.call("pta_engine_rn_coef", self.seed, r0 + lo, n, self.P, self.K, dv.ptr(self.d_amp), dv.ptr(ws["coef"]), int(self.rng_fast), s)
+                pl.rn_coef = ws["coef"].data_ptr()
+            _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * self.P, dv.ptr(ws["G0"]), pl.gw_npts, s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), self.P, dv.ptr(ws["G0"]), n, pl.gw_npts, pl.gw_npts, dv.ptr(ws["G"]), int(self.mix_variant), s)
+            pl.gw_G = ws["G"].data_ptr()
+            _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0 + lo, n, optr, out.stride(0), s)
         # per-kernel callers (bench.py, replay) read the workspace pointers from the plan
         if self.plan.rn_k:
             self.plan.rn_coef = ws["coef"].data_ptr()
@@ -371,39 +414,39 @@ class ReplicaEngine(TimeDomainMixin):
         switched off reproduces exactly the deviates of the combined pass."""
         if not self._prepared:
             self.prepare()
-        if R > 65536:
-            raise ValueError("generate_per_signal: at most 65536 realisations per call")
+        if R > self.max_batch():
+            raise ValueError(f"generate_per_signal: at most {self.max_batch()} realisations per call (one workspace batch)")
         total = self.generate(R, r0=r0)                      # also fills the workspace (coefficients, mixed GWB grid series)
-        pl, s = self.plan, dv.stream_ptr()
-        keep = (pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det)
+        s = dv.stream_ptr()
+        keep = (self.plan.rn_k, self.plan.gw_npts, self.plan.wn_a, self.plan.wn_b, self.plan.ecorr_toa, self.plan.epoch_of, self.plan.det)
         out = {"total": total}
-        try:
-            def one(name, **on):
-                pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = (
-                    on.get("rn_k", 0), on.get("gw_npts", 0), on.get("wn_a"), on.get("wn_b"), on.get("ecorr_toa"),
-                    on.get("epoch_of"), on.get("det"))
-                buf = dv.empty((R, self.n_toa))
-                _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(buf), buf.stride(0), s)
-                out[name] = buf
-            if keep[0]:
-                one("rn", rn_k=keep[0])
-            if keep[1]:
-                one("gwb", gw_npts=keep[1])
-            if keep[2]:
-                one("wn", wn_a=keep[2], wn_b=keep[3])
-            if keep[4]:
-                one("ecorr", ecorr_toa=keep[4], epoch_of=keep[5])
-            if keep[6]:
-                out["det"] = self.d_det.unsqueeze(0).expand(R, self.n_toa)
-        finally:
-            pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = keep
+
+        def one(name, **on):
+            pl = _lib.EnginePlan.from_buffer_copy(self.plan)   # a private copy: the shared plan is never mutated
+            pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = (
+                on.get("rn_k", 0), on.get("gw_npts", 0), on.get("wn_a"), on.get("wn_b"), on.get("ecorr_toa"),
+                on.get("epoch_of"), on.get("det"))
+            buf = dv.empty((R, self.n_toa))
+            _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(buf), buf.stride(0), s)
+            out[name] = buf
+        if keep[0]:
+            one("rn", rn_k=keep[0])
+        if keep[1]:
+            one("gwb", gw_npts=keep[1])
+        if keep[2]:
+            one("wn", wn_a=keep[2], wn_b=keep[3])
+        if keep[4]:
+            one("ecorr", ecorr_toa=keep[4], epoch_of=keep[5])
+        if keep[6]:
+            out["det"] = self.d_det.unsqueeze(0).expand(R, self.n_toa)
         return out
 
     def stream_to_host(self, total, chunk=480, r0=0):
         """Generator over (first_realisation, host_array[n, n_toa]) covering realisations r0 .. r0+total-1: generation on
         the current stream, device->host copies of the previous chunk on a second stream into two pinned buffers, so the
         PCIe link (2.72 MB per realisation at 68 x 5000) is the only thing waited for.  The yielded array is a view of a
-        pinned buffer that is reused two chunks later - copy it if it must outlive the next two iterations."""
+        pinned buffer and is valid ONLY until the generator is resumed: asking for the next chunk immediately queues the copy
+        of chunk k+2 into the very buffer chunk k was yielded from - copy the array if it must outlive the next next()."""
         if not self._prepared:
             self.prepare()
         chunk = int(min(chunk, total))
@@ -447,21 +490,21 @@ class ReplicaEngine(TimeDomainMixin):
             buf = dv.empty((self.P, 2 * Nf))
             for a in range(self.P):
                 _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_GWB, a), Nf, 1,
-                          ctypes.c_void_p(buf.data_ptr() + 16 * Nf * a), None, 2 * Nf, s)
+                          ctypes.c_void_p(buf.data_ptr() + 16 * Nf * a), None, 2 * Nf, int(self.rng_fast), s)
             w = buf.cpu().numpy().reshape(self.P, Nf, 2)
             d["gwb"] = w[:, :, 0] + 1j * w[:, :, 1]
         if self.plan.rn_k:
             d["rn"] = []
             for a in range(self.P):
                 buf = dv.empty((self.K,))
-                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_RN, a), self.K // 2, 1, dv.ptr(buf), None, self.K, s)
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_RN, a), self.K // 2, 1, dv.ptr(buf), None, self.K, int(self.rng_fast), s)
                 d["rn"].append(buf.cpu().numpy())
         if self.plan.wn_a:
             d["wn"] = []
             for a in range(self.P):
                 n = int(self.counts[a])
                 z1, z2 = dv.empty((n,)), dv.empty((n,))
-                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_WN, a), n, 0, dv.ptr(z1), dv.ptr(z2), n, s)
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_WN, a), n, 0, dv.ptr(z1), dv.ptr(z2), n, int(self.rng_fast), s)
                 d["wn"].append((z1.cpu().numpy(), z2.cpu().numpy()))
         if self.plan.ecorr_toa:
             d["ecorr"] = []
@@ -469,7 +512,7 @@ class ReplicaEngine(TimeDomainMixin):
                 ne = len(self.ecorrvec[a])
                 npair = (ne + 1) // 2
                 buf = dv.empty((2 * npair,))
-                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_ECORR, a), npair, 1, dv.ptr(buf), None, 2 * npair, s)
+                _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_ECORR, a), npair, 1, dv.ptr(buf), None, 2 * npair, int(self.rng_fast), s)
                 d["ecorr"].append(buf.cpu().numpy()[:ne])
         return d
 
@@ -505,7 +548,7 @@ class ReplicaEngine(TimeDomainMixin):
             w_d = dv.f64(w)
             G0, G = dv.empty((R * P, npts)), dv.empty((R * P, npts))
             _lib.call("pta_gwb_idft", dv.ptr(w_d), 2 * Nf, R * P, Nf, dv.ptr(self.d_T), self.ldt, npts, dv.ptr(G0), npts, 1, s)
-            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), int(self.mix_variant), s)
             out = dv.empty((R, N))
             _lib.call("pta_gwb_interp", dv.ptr(G), npts, P, npts, dv.ptr(self.d_ut), dv.ptr(self.d_toa_s), dv.ptr(self.d_psr_of),
                       dv.ptr(self.d_jlo), N, R, ctypes.c_double(1.0), dv.ptr(out), N, 0, s)

@@ -97,40 +97,55 @@ class TimeDomainMixin:
         self.td_plan = tp
 
         # ---- GWB: factor of the grid covariance Sigma_g = T^T T (realisation independent, shared by all pulsars)
-        self.tdgw_plan = None
         if pl.gw_npts:
-            npts, Nf = pl.gw_npts, self.grid["Nf"]
-            ldg = (npts + 1) // 2 * 2
-            Sg = dv.zeros((npts, ldg))
-            _lib.call("pta_dgemm", 0, npts, npts, 2 * (Nf - 2), ctypes.c_double(1.0), dv.ptr(self.d_T), 1, self.ldt, dv.ptr(self.d_T),
-                      self.ldt, ctypes.c_double(0.0), dv.ptr(Sg), ldg, 1, 1, 0, 0, 0, 1, s)
-            self.Sg_td = Sg
-            ginfo = dv.zeros((1,), dtype=torch.int32)
-            mean_diag = float(torch.diagonal(Sg[:, :npts]).mean().item())
-            eps, self.gw_td_jitter = 0.0, 0.0
-            while True:
-                Lg = Sg.clone()
-                if eps:
-                    torch.diagonal(Lg[:, :npts]).add_(eps * mean_diag)
-                _lib.call("pta_potrf_batched_ex", dv.ptr(Lg), npts, ldg, npts * ldg, 1, dv.ptr(ginfo), _lib.POTRF_SUBSTITUTION, s)
-                if int(ginfo.item()) == 0:
-                    break
-                eps = 1e-14 if eps == 0.0 else eps * 10.0
-                if eps > 1e-8:
-                    raise np.linalg.LinAlgError("GWB grid covariance is not positive definite even with 1e-8 relative jitter")
-            self.gw_td_jitter = eps
-            self.d_Lg, self.td_ldg = Lg, ldg
-            gblk, gn0 = _strips([npts])
-            self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0)]
-            gp = _lib.TdPlan()
-            gp.Lbase = Lg.data_ptr()
-            gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0 = [x.data_ptr() for x in self._tdgw_keep]
-            gp.n_blocks, gp.n_items, gp.rows_per_real, gp.stream_kind, gp.rng_fast = 1, len(gblk), P, STREAM_TDGW, 0
-            self.tdgw_plan = gp
-            tp.gw_npts, tp.gw_jlo, tp.gw_w = npts, self.d_jlo.data_ptr(), self.d_gw_w.data_ptr()
+            self._prepare_gw_grid_factor()
+            tp.gw_npts, tp.gw_jlo, tp.gw_w = pl.gw_npts, self.d_jlo.data_ptr(), self.d_gw_w.data_ptr()
+        else:
+            self.tdgw_plan = None
+            self.gw_td_jitter = 0.0
         self._td_ws = None
         self._td_prepared = True
         return self
+
+    def _prepare_gw_grid_factor(self):
+        """Cholesky factor L_g of the covariance of the npts GWB grid samples of one pulsar, Sigma_g = T^T T (T the twiddle
+        matrix of the pruned inverse DFT with sqrt(C(f)) folded in, red_noise.py:265-285; equals the Toeplitz matrix of
+        SURVEY.md App. A.1) and the pta_td_plan that draws through it (rows = (realisation, pulsar), stream (TDGW, pulsar))."""
+        if getattr(self, "_gw_grid_ready", False):
+            return
+        if not self._prepared:
+            self.prepare()
+        pl, s, P = self.plan, dv.stream_ptr(), self.P
+        npts, Nf = pl.gw_npts, self.grid["Nf"]
+        ldg = (npts + 1) // 2 * 2
+        Sg = dv.zeros((npts, ldg))
+        _lib.call("pta_dgemm", 0, npts, npts, 2 * (Nf - 2), ctypes.c_double(1.0), dv.ptr(self.d_T), 1, self.ldt, dv.ptr(self.d_T),
+                  self.ldt, ctypes.c_double(0.0), dv.ptr(Sg), ldg, 1, 1, 0, 0, 0, 1, s)
+        self.Sg_td = Sg
+        ginfo = dv.zeros((1,), dtype=torch.int32)
+        mean_diag = float(torch.diagonal(Sg[:, :npts]).mean().item())
+        eps = 0.0
+        while True:
+            Lg = Sg.clone()
+            if eps:
+                torch.diagonal(Lg[:, :npts]).add_(eps * mean_diag)
+            # forward-substitution panel solves: LAPACK-grade backward error on this cond ~ 3e14 matrix
+            _lib.call("pta_potrf_batched_ex", dv.ptr(Lg), npts, ldg, npts * ldg, 1, dv.ptr(ginfo), _lib.POTRF_SUBSTITUTION, s)
+            if int(ginfo.item()) == 0:
+                break
+            eps = 1e-14 if eps == 0.0 else eps * 10.0
+            if eps > 1e-8:
+                raise np.linalg.LinAlgError("GWB grid covariance is not positive definite even with 1e-8 relative jitter")
+        self.gw_td_jitter = eps
+        self.d_Lg, self.td_ldg = Lg, ldg
+        gblk, gn0 = _strips([npts])
+        self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0)]
+        gp = _lib.TdPlan()
+        gp.Lbase = Lg.data_ptr()
+        gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0 = [x.data_ptr() for x in self._tdgw_keep]
+        gp.n_blocks, gp.n_items, gp.rows_per_real, gp.stream_kind, gp.rng_fast = 1, len(gblk), P, STREAM_TDGW, 0
+        self.tdgw_plan = gp
+        self._gw_grid_ready = True
 
     # ---------------------------------------------------------------- generate ------------------
     def generate_td(self, R, r0=0, out=None, chunk=4096):
@@ -142,6 +157,9 @@ class TimeDomainMixin:
         s = dv.stream_ptr()
         P, npts = self.P, self.plan.gw_npts
         tp = self.td_plan
+        tp.rng_fast = int(self.rng_fast)
+        if self.tdgw_plan is not None:
+            self.tdgw_plan.rng_fast = int(self.rng_fast)
         chunk = int(min(chunk, R))
         if npts:
             ws = self._td_ws
@@ -152,7 +170,7 @@ class TimeDomainMixin:
             n = min(chunk, R - lo)
             if npts:
                 _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(ws[0]), npts, s)
-                _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), s)
+                _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), int(self.mix_variant), s)
             _lib.call("pta_td_trmm_rng", ctypes.byref(tp), self.seed, r0 + lo, n, ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)),
                       out.stride(0), s)
         return out
@@ -169,7 +187,7 @@ class TimeDomainMixin:
             n = int(self.counts[a])
             npair = (n + 1) // 2
             buf = dv.empty((2 * npair,))
-            _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_TD, a), npair, 1, dv.ptr(buf), None, 2 * npair, s)
+            _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_TD, a), npair, 1, dv.ptr(buf), None, 2 * npair, int(self.rng_fast), s)
             d["td"].append(buf.cpu().numpy()[:n])
         if self.plan.gw_npts:
             npts = self.plan.gw_npts
@@ -177,7 +195,7 @@ class TimeDomainMixin:
             buf = dv.empty((self.P, 2 * npair))
             for a in range(self.P):
                 _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_TDGW, a), npair, 1,
-                          ctypes.c_void_p(buf.data_ptr() + 16 * npair * a), None, 2 * npair, s)
+                          ctypes.c_void_p(buf.data_ptr() + 16 * npair * a), None, 2 * npair, int(self.rng_fast), s)
             d["gwb"] = buf.cpu().numpy()[:, :npts]
         return d
 
@@ -204,15 +222,15 @@ class TimeDomainMixin:
             n = int(self.counts[a])
             L = self.td_factor(a)
             z = dv.f64(np.stack([d["td"][a] for d in draws_list]))
-            _lib.call("pta_td_trmm", dv.ptr(L), n, n, dv.ptr(z), n, R, ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, s)
+            _lib.call("pta_td_trmm", dv.ptr(L), n, n, dv.ptr(z), n, R, ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, 1, s)
             torch.cuda.current_stream().synchronize()
         if self.plan.gw_npts:
             npts = self.plan.gw_npts
             Lg = self.gw_grid_factor()
             zg = dv.f64(np.stack([d["gwb"] for d in draws_list]).reshape(R * P, npts))
             G0, G = dv.empty((R * P, npts)), dv.empty((R * P, npts))
-            _lib.call("pta_td_trmm", dv.ptr(Lg), npts, npts, dv.ptr(zg), npts, R * P, dv.ptr(G0), npts, 0, s)
-            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), s)
+            _lib.call("pta_td_trmm", dv.ptr(Lg), npts, npts, dv.ptr(zg), npts, R * P, dv.ptr(G0), npts, 0, 1, s)
+            _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(G0), R, npts, npts, dv.ptr(G), 0, s)
             _lib.call("pta_gwb_interp", dv.ptr(G), npts, P, npts, dv.ptr(self.d_ut), dv.ptr(self.d_toa_s), dv.ptr(self.d_psr_of),
                       dv.ptr(self.d_jlo), N, R, ctypes.c_double(1.0), dv.ptr(out), N, 1, s)
         if self.plan.det:

@@ -129,8 +129,11 @@ def gwb_spectrum(f, dur, howml, log10_amplitude, spectral_index, turnover=False,
         if len(userSpec[:, 0]) != len(freqs):
             raise ValueError("Number of supplied spectral points does not match number of frequencies!")
         # log-log linear interpolation, flat outside the supplied band (interp1d + extrap1d, :11-33,261-263);
-        # numpy.interp is what scipy's interp1d(kind='linear') delegates to, and clamps at the ends
-        hcf = 10.0 ** np.interp(np.log10(f), np.log10(freqs), np.log10(userSpec[:, 1]))
+        # numpy.interp is what scipy's interp1d(kind='linear') delegates to, and clamps at the ends.  interp1d
+        # (assume_sorted=False) first sorts the supplied points by frequency (stable mergesort) - numpy.interp would
+        # silently return garbage for an unsorted spectrum - so do the same
+        order = np.argsort(freqs, kind="mergesort")
+        hcf = 10.0 ** np.interp(np.log10(f), np.log10(freqs[order]), np.log10(userSpec[order, 1]))
     return 1 / 96 / np.pi ** 2 * hcf ** 2 / f ** 3 * dur * howml
 
 
@@ -141,18 +144,19 @@ def gwb_orf_device(psrs, no_correlations=False, clm=(np.sqrt(4.0 * np.pi),), lma
         return dv.f64(np.diag(np.ones(P) * 2))
     psrlocs = np.zeros((P, 2))
     for ii in range(P):
-        psrlocs[ii] = ra_dec(psrs[ii])
+        psrlocs[ii] = ra_dec(psrs[ii], default=(0.0, 0.0))   # no location: stays (0, 0), like red_noise.py:203
     psrlocs[:, 1] = np.pi / 2.0 - psrlocs[:, 1]
     return anis.orf_from_locations(psrlocs, clm, lmax)
 
 
-def cholesky_device(A):
+def cholesky_device(A, flags=0):
     """lower Cholesky factor of a [n,n] (or [B,n,n]) device tensor, in place; raises numpy's LinAlgError
-    like np.linalg.cholesky (red_noise.py:235) when a matrix is not positive definite."""
+    like np.linalg.cholesky (red_noise.py:235) when a matrix is not positive definite.  `flags`: extra PTA_POTRF_* bits
+    (e.g. _lib.POTRF_VALU for the all-VALU cross-check path)."""
     batched = A.dim() == 3
     B, n = (A.shape[0], A.shape[1]) if batched else (1, A.shape[0])
     info = dv.zeros((B,), dtype=torch.int32)
-    _lib.call("pta_potrf_batched", dv.ptr(A), n, B, dv.ptr(info), dv.stream_ptr())
+    _lib.call("pta_potrf_batched_ex", dv.ptr(A), n, n, n * n, B, dv.ptr(info), _lib.POTRF_ZERO_UPPER | int(flags), dv.stream_ptr())
     bad = info.cpu().numpy()
     if np.any(bad != 0):
         raise np.linalg.LinAlgError("Matrix is not positive definite")
@@ -193,7 +197,7 @@ def add_gwb(psrs, log10_amplitude, spectral_index, no_correlations=False, seed=N
     G0 = dv.empty((Npulsars, npts))
     _lib.call("pta_gwb_idft", dv.ptr(w_d), 2 * Nf, Npulsars, Nf, dv.ptr(T), ldt, npts, dv.ptr(G0), npts, 1, s)
     G = dv.empty((Npulsars, npts))
-    _lib.call("pta_gwb_mix", dv.ptr(M), Npulsars, dv.ptr(G0), 1, npts, npts, dv.ptr(G), s)
+    _lib.call("pta_gwb_mix", dv.ptr(M), Npulsars, dv.ptr(G0), 1, npts, npts, dv.ptr(G), 0, s)
 
     toa_s = [psr.toas.get_mjds().value.astype(float) * 86400 for psr in psrs]
     counts = [len(t) for t in toa_s]

@@ -1,0 +1,13 @@
+"""one assemble + factorisation of the 68 x 5000^2 TD covariances (for rocprofv3 timelines)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import configure_engine, headline_array
+from pta_replicator_amd.engine import ReplicaEngine
+P, N = int(sys.argv[1]), int(sys.argv[2])
+look = sys.argv[3] != "0"
+psrs, noise = headline_array(P, N)
+eng = configure_engine(ReplicaEngine(psrs, seed=1), noise)
+eng._gw = None
+eng.prepare_td(lookahead=look)
+torch.cuda.synchronize()

@@ -7,7 +7,7 @@ from oracle import philox_ref
 
 seed, real, stream, npairs = 77, 5, philox_ref.stream_id(3, 11), 1 << 20
 z = dv.empty((2 * npairs,))
-_lib.call("pta_rng_fill_normal", seed, real, 1, stream, npairs, 1, dv.ptr(z), None, 2 * npairs, dv.stream_ptr())
+_lib.call("pta_rng_fill_normal", seed, real, 1, stream, npairs, 1, dv.ptr(z), None, 2 * npairs, 0, dv.stream_ptr())
 got = z.cpu().numpy()
 u1, u2 = philox_ref.uniform_pairs(seed, real, stream, npairs)
 L = np.longdouble

@@ -1,0 +1,60 @@
+"""Turn the rocprofv3 CSV passes of scripts/gpu_profile_r2.sh into profiles/r02_pmc.json: the PMC figures bench.py quotes
+(roofline.traffic, VALU issue, MFMA-busy %), each keyed by kernel + launch shape + a hash of the kernel sources."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import SYNTH_SRC, TD_SRC, src_sha
+
+out_dir, R, n_toa, n_psr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+
+
+def sums(pass_dir, match):
+    """mean per dispatch of every counter, over the dispatches of kernels whose name contains `match`"""
+    acc, disp = collections.Counter(), set()
+    for p in glob.glob(os.path.join(out_dir, pass_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if match in r["Kernel_Name"]:
+                acc[r["Counter_Name"]] += float(r["Counter_Value"])
+                disp.add((p, r["Dispatch_Id"]))
+    n = max(len(disp), 1)
+    return {k: v / n for k, v in acc.items()}, len(disp)
+
+
+def avg_ms(match):
+    tot, n = 0.0, 0
+    for p in glob.glob(os.path.join(out_dir, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if match in r["Kernel_Name"]:
+                tot += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+                n += 1
+    return (tot / n if n else None), n
+
+
+res = {}
+CU, SIMD = 256, 4
+# ---- fused synthesis kernel
+k = "k_engine_synth_mfma<false>"
+f, nf = sums("pmc_fetch", k)
+w, nw = sums("pmc_write", k)
+a, na = sums("pmc_sq", k)
+ms, nt = avg_ms(k)
+if nf and nw:
+    e = {"R": R, "n_toa": n_toa, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
+         "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*SYNTH_SRC),
+         "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
+    if na:
+        e["insts_valu"] = a.get("SQ_INSTS_VALU")
+        if a.get("GRBM_GUI_ACTIVE"):
+            e["valu_busy"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (a["GRBM_GUI_ACTIVE"] * CU * SIMD) if a.get("SQ_ACTIVE_INST_VALU") else None
+    res[k] = e
+# ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x SIMDs)
+for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov", "k_trsm_mfma"):
+    m, nm = sums("pmc_mfma", k)
+    ms, nt = avg_ms(k)
+    if nm and m.get("GRBM_GUI_ACTIVE"):
+        res[k] = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * CU * SIMD),
+                  "mfma_busy_cycles_per_dispatch": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active_cycles_per_dispatch": m["GRBM_GUI_ACTIVE"],
+                  "insts_valu_per_dispatch": m.get("SQ_INSTS_VALU"), "avg_launch_ms_rocprof": ms, "dispatches": nm, "src_sha": src_sha(*TD_SRC),
+                  "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
+json.dump(res, open(os.path.join(out_dir, "r02_pmc.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

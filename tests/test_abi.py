@@ -24,8 +24,10 @@ def test_header_declares_the_expected_surface():
     d = declared()
     for name in ("pta_rn_basis", "pta_rn_synth", "pta_wn", "pta_ecorr", "pta_quantize_epochs", "pta_orf_hd", "pta_orf_basis",
                  "pta_potrf_batched", "pta_gwb_twiddle", "pta_gwb_idft", "pta_gwb_idft_rng", "pta_gwb_mix", "pta_gwb_interp",
-                 "pta_cgw", "pta_engine_synth", "pta_td_cov_assemble", "pta_td_trmm", "pta_dgemm", "pta_rng_fill_normal"):
+                 "pta_cgw", "pta_engine_synth", "pta_td_cov_assemble", "pta_td_trmm", "pta_td_trmm_rng", "pta_potrf_batched_ex", "pta_dgemm",
+                 "pta_rng_fill_normal"):
         assert name in d, name
+    assert not [n for n in d if n.startswith("pta_set_")], "ABI 2 has no process-wide switches"
 
 
 def test_library_exports_every_declared_symbol():
@@ -43,7 +45,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_error_channel_without_gpu():
     from pta_replicator_amd import _lib
-    assert _lib.lib.pta_abi_version() == 1
+    assert _lib.lib.pta_abi_version() == 2
     rc = _lib.lib.pta_quantize_epochs(None, 0, 1.0, None, None, None, None)
     assert rc == -1 and "NULL" in _lib.last_error()
     with pytest.raises(_lib.PtaError):
@@ -66,7 +68,7 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "hdr.c"
-    src.write_text('#include "pta_replicator_amd.h"\nint main(void){ pta_engine_plan p; pta_engine_tables t; (void)p; (void)t; return PTA_OK; }\n')
+    src.write_text('#include "pta_replicator_amd.h"\nint main(void){ pta_engine_plan p; pta_engine_tables t; pta_td_plan q; (void)p; (void)t; (void)q; return PTA_OK; }\n')
     for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
         if shutil.which(cc) is None:
             pytest.skip(cc + " not available")

@@ -49,11 +49,11 @@ def test_rng_fill_matches_numpy_twin(gpu, interleave):
     sid = philox_ref.stream_id(philox_ref.STREAM_WN, 17)
     if interleave:
         z0 = dv.empty((R, 2 * npairs)); z1 = None
-        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 1, dv.ptr(z0), None, 2 * npairs, gpu["s"])
+        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 1, dv.ptr(z0), None, 2 * npairs, 0, gpu["s"])
         got0, got1 = z0.cpu().numpy()[:, 0::2], z0.cpu().numpy()[:, 1::2]
     else:
         z0, z1 = dv.empty((R, npairs)), dv.empty((R, npairs))
-        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 0, dv.ptr(z0), dv.ptr(z1), npairs, gpu["s"])
+        lib.call("pta_rng_fill_normal", seed, r0, R, sid, npairs, 0, dv.ptr(z0), dv.ptr(z1), npairs, 0, gpu["s"])
         got0, got1 = z0.cpu().numpy(), z1.cpu().numpy()
     for r in range(R):
         e0, e1 = philox_ref.normal_pairs(seed, r0 + r, sid, npairs)
@@ -66,12 +66,8 @@ def test_fast_rng_math_mode(gpu):
     seed, npairs = 4242, 200000
     sid = philox_ref.stream_id(philox_ref.STREAM_WN, 3)
     acc, fast = dv.empty((2 * npairs,)), dv.empty((2 * npairs,))
-    lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(acc), None, 2 * npairs, gpu["s"])
-    lib.call("pta_set_rng_math", 1)
-    try:
-        lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(fast), None, 2 * npairs, gpu["s"])
-    finally:
-        lib.call("pta_set_rng_math", 0)
+    lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(acc), None, 2 * npairs, 0, gpu["s"])
+    lib.call("pta_rng_fill_normal", seed, 9, 1, sid, npairs, 1, dv.ptr(fast), None, 2 * npairs, 1, gpu["s"])   # rng_fast = 1, per call
     a, f = acc.cpu().numpy(), fast.cpu().numpy()
     assert np.max(np.abs(a - f)) < 2e-5 and np.sqrt(np.mean((a - f) ** 2)) < 2e-6
     z0, z1 = philox_ref.normal_pairs(seed, 9, sid, npairs, fast=True)
@@ -139,13 +135,11 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
     rng = np.random.default_rng(n)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
-    for algo in (0, 1):
-        lib.call("pta_set_gemm_algo", algo)
-        L = rn.cholesky_device(dv.f64(A)).cpu().numpy()
+    for flags in (lib.POTRF_VALU, 0, lib.POTRF_SUBSTITUTION, lib.POTRF_NO_LOOKAHEAD):   # VALU cross-check, default (MFMA), ...
+        L = rn.cholesky_device(dv.f64(A), flags).cpu().numpy()
         ref = np.linalg.cholesky(A)
-        assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, algo)
+        assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, flags)
         assert np.all(np.triu(L, 1) == 0)
-    lib.call("pta_set_gemm_algo", 1)
 
 
 def test_potrf_not_positive_definite_raises(gpu):
@@ -199,19 +193,17 @@ def test_gwb_idft_rng_equals_replay_of_its_draws(gpu, variant, Nf, npts):
     T = dv.empty((2 * (Nf - 2), ldt))
     sq_d = dv.f64(C ** 0.5)
     lib.call("pta_gwb_twiddle", dv.ptr(sq_d), Nf, npts, 10, 1.0 / 777.0, dv.ptr(T), ldt, gpu["s"])
-    lib.call("pta_set_idft_variant", variant)
     nrot = ctypes.c_int64(0)
-    nsym = lib.lib.pta_gwb_twiddle_sym_size(Nf, npts, ctypes.byref(nrot))
+    nsym = lib.lib.pta_gwb_twiddle_sym_size(Nf, npts, variant, ctypes.byref(nrot))
     Tsym, rot = dv.empty((nsym,)), dv.empty((nrot.value,))
-    lib.call("pta_gwb_twiddle_sym", dv.ptr(sq_d), Nf, npts, 10, 1.0 / 777.0, dv.ptr(Tsym), dv.ptr(rot), gpu["s"])
+    lib.call("pta_gwb_twiddle_sym", dv.ptr(sq_d), Nf, npts, 10, 1.0 / 777.0, dv.ptr(Tsym), dv.ptr(rot), variant, gpu["s"])
     G_rng = dv.zeros((R * P, npts))
-    lib.call("pta_gwb_idft_rng", seed, r0, R, P, Nf, dv.ptr(Tsym), dv.ptr(rot), npts, dv.ptr(G_rng), npts, gpu["s"])
-    lib.call("pta_set_idft_variant", 1)
+    lib.call("pta_gwb_idft_rng", seed, r0, R, P, Nf, dv.ptr(Tsym), dv.ptr(rot), npts, dv.ptr(G_rng), npts, variant, 0, gpu["s"])
     w = dv.empty((R * P, 2 * Nf))
     for r in range(R):
         for a in range(P):
             lib.call("pta_rng_fill_normal", seed, r0 + r, 1, philox_ref.stream_id(1, a), Nf, 1,
-                     ctypes.c_void_p(w.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, gpu["s"])
+                     ctypes.c_void_p(w.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, 0, gpu["s"])
     G_rep = dv.zeros((R * P, npts))
     lib.call("pta_gwb_idft", dv.ptr(w), 2 * Nf, R * P, Nf, dv.ptr(T), ldt, npts, dv.ptr(G_rep), npts, 1, gpu["s"])
     a, b = G_rng.cpu().numpy(), G_rep.cpu().numpy()
@@ -229,7 +221,6 @@ def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts, variant):
     dumped draws."""
     dv, lib = gpu["dv"], gpu["lib"]
     assert lib.lib.pta_gwb_czt_fits(Nf, npts, 10) == 1 and lib.lib.pta_gwb_czt_fits(5000, 1000, 10) == 0
-    lib.call("pta_set_czt_variant", variant)
     rng = np.random.default_rng(Nf)
     seed, r0, R, P = 99, 12345, 2, 3
     M = R * P
@@ -241,26 +232,25 @@ def test_gwb_chirp_z_fft_vs_numpy_and_vs_dft_gemm(gpu, Nf, npts, variant):
     w = rng.standard_normal((M, Nf, 2))
     w_d = dv.f64(w)
     G = dv.zeros((M, npts))
-    lib.call("pta_gwb_czt", 0, 0, dv.ptr(w_d), 2 * Nf, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G), npts, gpu["s"])
+    lib.call("pta_gwb_czt", 0, 0, dv.ptr(w_d), 2 * Nf, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G), npts, variant, 0, gpu["s"])
     Res_f = (w[..., 0] + 1j * w[..., 1]) * C ** 0.5
     Res_f[:, 0] = 0; Res_f[:, -1] = 0
     ref = po.gwb_time_series(Res_f, dt)[:, 10:npts + 10]
     assert np.max(np.abs(G.cpu().numpy() - ref)) < 1e-12 * np.max(np.abs(ref))
     # throughput form against the plain DFT-GEMM on its own draws
     G_rng = dv.zeros((M, npts))
-    lib.call("pta_gwb_czt", seed, r0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G_rng), npts, gpu["s"])
+    lib.call("pta_gwb_czt", seed, r0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in tabs], dv.ptr(G_rng), npts, variant, 0, gpu["s"])
     wd = dv.empty((M, 2 * Nf))
     for r in range(R):
         for a in range(P):
             lib.call("pta_rng_fill_normal", seed, r0 + r, 1, philox_ref.stream_id(1, a), Nf, 1,
-                     ctypes.c_void_p(wd.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, gpu["s"])
+                     ctypes.c_void_p(wd.data_ptr() + 16 * Nf * (r * P + a)), None, 2 * Nf, 0, gpu["s"])
     ldt = (npts + 15) // 16 * 16
     T = dv.empty((2 * (Nf - 2), ldt))
     lib.call("pta_gwb_twiddle", dv.ptr(sq_d), Nf, npts, 10, 1.0 / dt, dv.ptr(T), ldt, gpu["s"])
     G_rep = dv.zeros((M, npts))
     lib.call("pta_gwb_idft", dv.ptr(wd), 2 * Nf, M, Nf, dv.ptr(T), ldt, npts, dv.ptr(G_rep), npts, 1, gpu["s"])
     a_, b_ = G_rng.cpu().numpy(), G_rep.cpu().numpy()
-    lib.call("pta_set_czt_variant", 0)
     assert np.max(np.abs(a_ - b_)) < 1e-12 * np.max(np.abs(b_))
 
 
@@ -295,12 +285,12 @@ def test_td_mode_against_oracle(gpu):
     z = rng.standard_normal((R, N))
     out = dv.zeros((R, N))
     z_d = dv.f64(z)
-    lib.call("pta_td_trmm", dv.ptr(L), N, N, dv.ptr(z_d), N, R, dv.ptr(out), N, 0, gpu["s"])
+    lib.call("pta_td_trmm", dv.ptr(L), N, N, dv.ptr(z_d), N, R, dv.ptr(out), N, 0, 1, gpu["s"])
     ref = po.td_draw(Cref, z.T).T
     assert np.max(np.abs(out.cpu().numpy() - ref)) < 1e-8 * np.sqrt(np.mean(ref ** 2))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("P,npts,R,ldg", [(68, 600, 5, 600), (3, 50, 1, 50), (16, 64, 9, 64), (17, 65, 4, 72), (80, 601, 3, 608), (81, 100, 2, 100),
                                           (200, 120, 2, 120), (1, 7, 6, 7)])
 def test_gwb_mix_against_numpy(gpu, P, npts, R, ldg, variant):
@@ -312,11 +302,7 @@ def test_gwb_mix_against_numpy(gpu, P, npts, R, ldg, variant):
     G0 = rng.standard_normal((R, P, ldg))
     M_d, G0_d = dv.f64(M), dv.f64(G0)
     G_d = dv.f64(np.full((R, P, ldg), 7.0))
-    lib.call("pta_set_mix_variant", variant)
-    try:
-        lib.call("pta_gwb_mix", dv.ptr(M_d), P, dv.ptr(G0_d), R, npts, ldg, dv.ptr(G_d), gpu["s"])
-    finally:
-        lib.call("pta_set_mix_variant", 0)
+    lib.call("pta_gwb_mix", dv.ptr(M_d), P, dv.ptr(G0_d), R, npts, ldg, dv.ptr(G_d), variant, gpu["s"])
     G = G_d.cpu().numpy()
     ref = np.einsum("ab,rbj->raj", M, G0[:, :, :npts])
     assert np.max(np.abs(G[:, :, :npts] - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))

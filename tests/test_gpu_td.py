@@ -53,18 +53,19 @@ def _normals(gpu, seed, r, kind, psr, n):
     lib, dv = gpu["lib"], gpu["dv"]
     npair = (n + 1) // 2
     buf = dv.empty((2 * npair,))
-    lib.call("pta_rng_fill_normal", seed, r, 1, philox_ref.stream_id(kind, psr), npair, 1, dv.ptr(buf), None, 2 * npair, gpu["s"])
+    lib.call("pta_rng_fill_normal", seed, r, 1, philox_ref.stream_id(kind, psr), npair, 1, dv.ptr(buf), None, 2 * npair, 0, gpu["s"])
     return buf.cpu().numpy()[:n]
 
 
-@pytest.mark.parametrize("sizes,R", [((1, 17, 256, 257), 5), ((300, 333, 513), 70), ((1024,), 64), ((2,), 1)])
+@pytest.mark.parametrize("sizes,R", [((1, 17, 256, 257), 5), ((300, 333, 513), 70), ((1024,), 64), ((2,), 1), ((4200, 4100, 4300, 4250), 3)])
 def test_td_trmm_rng_per_pulsar_blocks(gpu, sizes, R):
     """out[m, off_b + i] = sum_{j <= i} L_b[i, j] z(m, b, j) with z generated in registers: ragged factor orders (strip
     remainders, a 1 x 1 factor), odd orders with padded leading dimensions, realisation counts off the 64-row groups, NaN above
-    the diagonals (never read)."""
+    the diagonals (never read).  The last case has 68 strips: from 64 on, whole strips are dealt to the XCDs (the launch order
+    of the 68 x 5000 array); below, every XCD takes a share of every strip's row groups."""
     lib, dv = gpu["lib"], gpu["dv"]
     rng = np.random.default_rng(sum(sizes) + R)
-    Ls = [np.tril(rng.standard_normal((n, n))) + 3 * np.eye(n) for n in sizes]
+    Ls = [np.tril(rng.standard_normal((n, n))) / np.sqrt(n) + 3 * np.eye(n) for n in sizes]
     lds = [(n + 1) // 2 * 2 + (2 if b % 2 else 0) for b, n in enumerate(sizes)]
     keep = []
     tp, off = _plan(gpu, Ls, lds, 1, 5, keep)
@@ -219,9 +220,9 @@ def test_td_engine_gwb_part():
 
 
 def test_td_and_throughput_mode_have_the_same_ensemble_covariance():
-    """TD mode and throughput mode draw from the same Gaussian: sample covariances of 16384 realisations each (two pulsars,
-    RN + EFAC/EQUAD + ECORR + GWB) agree element by element within sampling error, and with the analytic covariance
-    C_a (+ ORF_ab A_a Sigma_g A_b^T for the GWB)."""
+    """TD mode, throughput mode and throughput mode with grid-drawn GWB draw from the same Gaussian: sample covariances of
+    16384 realisations each (two pulsars, RN + EFAC/EQUAD + ECORR + GWB) agree element by element within sampling error with
+    the analytic covariance C_a (+ ORF_ab A_a Sigma_g A_b^T for the GWB)."""
     import torch
     from pta_replicator_amd.engine import ReplicaEngine
     from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
@@ -241,8 +242,13 @@ def test_td_and_throughput_mode_have_the_same_ensemble_covariance():
     eng.prepare_td()
     x_td = eng.generate_td(R)
     x_fd = eng.generate(R)
+    eng.gwb_mode = "grid"                 # throughput mode with the GWB drawn on the grid (npts deviates per pulsar)
+    x_gr = eng.generate(R)
+    eng.gwb_mode = "fourier"
+    assert torch.equal(eng.generate(3), x_fd[:3])          # the default path is untouched by the mode switch
     c_td = (x_td.T @ x_td / R).cpu().numpy()
     c_fd = (x_fd.T @ x_fd / R).cpu().numpy()
+    c_gr = (x_gr.T @ x_gr / R).cpu().numpy()
     # analytic covariance
     n = eng.n_toa
     Cm = np.zeros((n, n))
@@ -263,7 +269,7 @@ def test_td_and_throughput_mode_have_the_same_ensemble_covariance():
             sb = slice(eng.off[b], eng.off[b + 1])
             Cm[sa, sb] += orf[a, b] * (A[a] @ S @ A[b].T)
     d = np.sqrt(np.diag(Cm))
-    for emp in (c_td, c_fd):
+    for emp in (c_td, c_fd, c_gr):
         assert np.max(np.abs(emp - Cm) / np.outer(d, d)) < 6.0 / np.sqrt(R)
     assert abs(np.trace(c_td) / np.trace(c_fd) - 1) < 0.03
 
