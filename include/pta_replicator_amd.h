@@ -120,14 +120,20 @@ int pta_orf_combine(const double *basis, const double *clm, int nbasis, int P, d
 int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 
 /* The same factorisation for matrices with a leading dimension and a batch stride: matrix b is row-major at A + b * strideA
- * with row pitch lda >= n.  flags: PTA_POTRF_ZERO_UPPER zeroes the strict upper triangle (np.linalg.cholesky's result);
- * without it the upper triangle is left holding scratch (the parked inverses of the diagonal blocks) - all TD mode needs,
- * since pta_td_trmm_rng reads the lower triangle only.  For n > 512 the schedule uses look-ahead: the next panel is factored
- * on an internal high-priority stream while the bulk of the trailing update runs on a second internal stream (both created on
- * first use and joined back into `stream` before returning; results are identical); PTA_POTRF_NO_LOOKAHEAD keeps every
- * launch on `stream` (A/B timing).                                                                                  */
+ * with row pitch lda >= n.  Schedule: right-looking over panels of NB = 1024 columns whose trailing update runs with K = NB
+ * (the 128 x 128-tile fp64 MFMA GEMM reaches 56 TFLOP/s at K = 1024 against 36-40 at K = 256); each panel is factored
+ * RECURSIVELY - left half, update of the right half with K = half the width, right half - down to 64 columns, where the
+ * diagonal block is factored and inverted in registers and the rows below are solved by an MFMA product with that inverse.
+ * A batch is split into two independent chains of matrices on internal streams (created on first use, joined back into
+ * `stream` before returning), so that one chain's serial, memory-bound panel steps overlap the other's MFMA-bound updates.
+ * flags: PTA_POTRF_ZERO_UPPER zeroes the strict upper triangle (np.linalg.cholesky's result); without it the upper triangle
+ * is left holding scratch (the parked inverses of the diagonal blocks) - all TD mode needs, since pta_td_trmm_rng reads the
+ * lower triangle only.  PTA_POTRF_NO_LOOKAHEAD keeps every launch on `stream` (one chain).  PTA_POTRF_NB(k) overrides the
+ * panel width with k * 256 columns, PTA_POTRF_CHAINS(c) the number of chains (1..4) - both for A/B timing.             */
 #define PTA_POTRF_ZERO_UPPER 1
 #define PTA_POTRF_NO_LOOKAHEAD 2
+#define PTA_POTRF_NB(k) (((k) & 0xFF) << 8) /* panel width override, in units of 256 columns */
+#define PTA_POTRF_CHAINS(c) (((c) & 0xF) << 16) /* number of concurrent chains of matrices (default 2) */
 #define PTA_POTRF_VALU 8          /* cross-check: VALU reference GEMM and substitution panel solve instead of the MFMA kernels */
 #define PTA_POTRF_SUBSTITUTION 4  /* panel solves by forward substitution instead of the MFMA product with the inverted diagonal
                                      block: LAPACK-grade backward error also when the diagonal blocks are very ill-conditioned

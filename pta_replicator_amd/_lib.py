@@ -108,6 +108,16 @@ ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
 TD_STRIP = 256      # PTA_TD_STRIP
 POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION, POTRF_VALU = 1, 2, 4, 8
 
+
+def POTRF_CHAINS(c):
+    """PTA_POTRF_CHAINS(c): number of concurrent chains of matrices of pta_potrf_batched_ex."""
+    return (int(c) & 0xF) << 16
+
+
+def POTRF_NB(k):
+    """PTA_POTRF_NB(k): panel width override of pta_potrf_batched_ex, k * 256 columns."""
+    return (int(k) & 0xFF) << 8
+
 EXPORTS = tuple(_SIGNATURES)
 
 for _name, (_res, _args) in _SIGNATURES.items():

@@ -231,11 +231,12 @@ __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t
 }
 
 
-// Side stream + events of the look-ahead schedule below, created on first use for the calling thread's current device.
+// Internal streams + events of the chained schedule below, created on first use for the calling thread's current device.
+#define PTA_POTRF_MAX_CHAINS 4
 struct pta_potrf_ctx {
   int dev = -1;
-  hipStream_t panel = nullptr, bulk = nullptr;
-  hipEvent_t ev_in = nullptr, ev_f = nullptr, ev_b = nullptr, ev_out_p = nullptr, ev_out_b = nullptr;
+  hipStream_t chain[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_in = nullptr, ev_out[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
 };
 static thread_local pta_potrf_ctx g_potrf_ctx;
 
@@ -244,27 +245,72 @@ static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
   PTA_HIP(hipGetDevice(&dev));
   pta_potrf_ctx &c = g_potrf_ctx;
   if (c.dev != dev) {
-    int lo = 0, hi = 0;  // numerically lower = higher priority
-    PTA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    PTA_HIP(hipStreamCreateWithPriority(&c.panel, hipStreamNonBlocking, hi));
-    PTA_HIP(hipStreamCreateWithPriority(&c.bulk, hipStreamNonBlocking, lo));
-    hipEvent_t *evs[5] = {&c.ev_in, &c.ev_f, &c.ev_b, &c.ev_out_p, &c.ev_out_b};
-    for (hipEvent_t *e : evs) PTA_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int i = 0; i < PTA_POTRF_MAX_CHAINS; ++i) {
+      PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
+      PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
+    }
+    PTA_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
     c.dev = dev;
   }
   *out = &c;
   return PTA_OK;
 }
 
-// Two-level right-looking blocking with look-ahead.  Outer panels are 256 columns wide; inside a panel, 64-wide steps
-// (diagonal block in registers -> MFMA panel solve -> update of the panel's remaining columns only).  The trailing update of
-// outer panel p is split in two:
-//   N(p): the next panel's 256 columns, on the (high-priority) panel stream, straight after the panel factorisation F(p);
-//   B(p): everything right of them (K = 256, 128 x 128 MFMA tiles over the lower-triangular tiles), on the bulk stream.
-// F(p+1) needs N(p) and B(<= p-1) only, so it runs WHILE B(p) keeps the matrix cores busy: the panel steps are short, serial
-// and memory bound (potf2 on one workgroup per matrix; the panel solve reads and writes the panel once), the bulk update is
-// MFMA bound - the two complement each other.  Hazards: N(p+1) and B(p) both accumulate into panel p+2's columns, so N(p+1)
-// waits for B(p); B(p+1) follows B(p) in stream order and waits for F(p+1).
+// Factor columns [c0, c0 + w) of every matrix of the batch for ALL rows below them, all updates from columns < c0 already
+// applied: recursive halving.  The right half of a panel is updated with K = the left half's width in ONE product (at the top
+// levels that is K = 512 / 256, where the MFMA GEMM runs at 47-50 / 36-40 TFLOP/s) instead of 64 columns at a time (K = 64: 16).
+// Base case (<= 64 columns): diagonal block factored AND inverted in registers (k_potf2), rows below solved by an MFMA product
+// with the parked inverse (k_trsm_mfma) or, on request, by forward substitution (k_trsm).
+static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, int c0, int w, int32_t *info, int flags, int algo,
+                            hipStream_t sp) {
+  if (w <= CH_NB) {
+    hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, info);
+    PTA_LAUNCH_CHECK();
+    const int rows = n - c0 - w;
+    if (rows <= 0) return PTA_OK;
+    if (algo && !(flags & PTA_POTRF_SUBSTITUTION))
+      hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
+    else
+      hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
+    PTA_LAUNCH_CHECK();
+    return PTA_OK;
+  }
+  const int w1 = ((w / 2 + CH_NB - 1) / CH_NB) * CH_NB;  // left half: a multiple of 64, < w
+  int rc = pta_factor_panel(A, n, lda, sA, B, c0, w1, info, flags, algo, sp);
+  if (rc != PTA_OK) return rc;
+  const int rows = n - (c0 + w1), cols = w - w1;
+  const double *L21 = A + (int64_t)(c0 + w1) * lda + c0;
+  double *A22 = A + (int64_t)(c0 + w1) * lda + (c0 + w1);
+  rc = pta_dgemm_launch(1, rows, cols, w1, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, sA, sA, sA, algo, sp);
+  if (rc != PTA_OK) return rc;
+  return pta_factor_panel(A, n, lda, sA, B, c0 + w1, cols, info, flags, algo, sp);
+}
+
+// One dependency chain: right-looking over panels of NBO columns, every launch on `s`.
+static int pta_potrf_chain(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO,
+                           hipStream_t s) {
+  for (int k0 = 0; k0 < n; k0 += NBO) {
+    const int nbo = (n - k0 < NBO) ? (n - k0) : NBO;
+    const int pend = k0 + nbo;  // one past the panel's last column
+    int rc = pta_factor_panel(A, n, lda, strideA, B, k0, nbo, info, flags, algo, s);
+    if (rc != PTA_OK) return rc;
+    const int rows = n - pend;
+    if (rows <= 0) break;
+    const double *L21 = A + (int64_t)pend * lda + k0;
+    double *A22 = A + (int64_t)pend * lda + pend;
+    rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
+    if (rc != PTA_OK) return rc;
+  }
+  return PTA_OK;
+}
+
+// Right-looking over panels of NB = 1024 columns; the trailing update of a panel is ONE product with K = NB over the
+// lower-triangular 128 x 128 tiles.  A batch is split into up to four independent CHAINS of matrices, each on its own
+// internal stream: the panel steps of a chain are short, serial and partly memory bound (potf2 on one workgroup per matrix;
+// each 64-column solve reads and writes its panel once) while its trailing updates are MFMA bound, so letting the hardware
+// interleave the chains fills one chain's panel phases with another chain's matrix-core work - look-ahead across the batch
+// instead of inside one matrix (an in-matrix look-ahead, next panel on a high-priority stream beside the bulk update, measured
+// slower: it splits every trailing update in two and the concurrent halves slow each other down).
 extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,
                                     void *stream) {
   PTA_REQUIRE(A && info, PTA_E_ARG, "pta_potrf_batched: NULL argument");
@@ -272,81 +318,31 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
   PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
               (long long)lda, (long long)strideA);
   hipStream_t s = pta_stream(stream);
-  const int g_gemm_algo = (flags & PTA_POTRF_VALU) ? 0 : 1;  // VALU reference GEMM + substitution panel solve (cross-check)
-  const int NBO = 4 * CH_NB;
-  const bool look = !(flags & PTA_POTRF_NO_LOOKAHEAD) && g_gemm_algo && n > 2 * NBO;
-  pta_potrf_ctx *cx = nullptr;
-  hipStream_t sp = s, sb = s;  // panel / bulk streams (the caller's stream when there is nothing to overlap)
+  const int algo = (flags & PTA_POTRF_VALU) ? 0 : 1;  // 0: VALU reference GEMM + substitution panel solve (cross-check)
+  const int nbk = (flags >> 8) & 0xFF;
+  const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
+  int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
+  if (nchain == 0) nchain = 2;
+  if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
+  if (nchain > B) nchain = B;
+  if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
-  if (look) {
+  if (nchain == 1) {
+    int rc = pta_potrf_chain(A, n, lda, strideA, B, info, flags, algo, NBO, s);
+    if (rc != PTA_OK) return rc;
+  } else {
+    pta_potrf_ctx *cx = nullptr;
     int rc = pta_potrf_ctx_get(&cx);
     if (rc != PTA_OK) return rc;
-    sp = cx->panel;
-    sb = cx->bulk;
     PTA_HIP(hipEventRecord(cx->ev_in, s));
-    PTA_HIP(hipStreamWaitEvent(sp, cx->ev_in, 0));
-    PTA_HIP(hipStreamWaitEvent(sb, cx->ev_in, 0));
-  }
-  bool bulk_pending = false;
-  for (int k0 = 0; k0 < n; k0 += NBO) {
-    const int nbo = (n - k0 < NBO) ? (n - k0) : NBO;
-    const int pend = k0 + nbo;  // one past the outer panel's last column
-    // ---- F(p): factor the outer panel, 64 columns at a time -------------------------------------------------------
-    for (int j0 = k0; j0 < pend; j0 += CH_NB) {
-      const int nb = (pend - j0 < CH_NB) ? (pend - j0) : CH_NB;
-      hipLaunchKernelGGL(k_potf2, dim3(B), dim3(256), 0, sp, A, lda, strideA, j0, nb, info);
-      PTA_LAUNCH_CHECK();
-      const int rows = n - j0 - nb;
-      if (rows <= 0) continue;
-      if (g_gemm_algo && !(flags & PTA_POTRF_SUBSTITUTION))
-        hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, strideA, j0, nb);
-      else
-        hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, strideA, j0, nb);
-      PTA_LAUNCH_CHECK();
-      const int pcols = pend - (j0 + nb);  // columns of the outer panel still to be factored
-      if (pcols > 0) {
-        const double *L21 = A + (int64_t)(j0 + nb) * lda + j0;
-        double *A22 = A + (int64_t)(j0 + nb) * lda + (j0 + nb);
-        int rc = pta_dgemm_launch(1, rows, pcols, nb, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, sp);
-        if (rc != PTA_OK) return rc;
-      }
-    }
-    const int rows = n - pend;
-    if (rows <= 0) break;
-    const double *L21 = A + (int64_t)pend * lda + k0;
-    double *A22 = A + (int64_t)pend * lda + pend;
-    if (!look) {
-      int rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, s);
+    for (int c = 0; c < nchain; ++c) {
+      const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
+      PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
+      rc = pta_potrf_chain(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, cx->chain[c]);
       if (rc != PTA_OK) return rc;
-      continue;
+      PTA_HIP(hipEventRecord(cx->ev_out[c], cx->chain[c]));
+      PTA_HIP(hipStreamWaitEvent(s, cx->ev_out[c], 0));  // join: the caller's stream continues after every chain
     }
-    // ---- B(p) on the bulk stream: columns right of the next panel ---------------------------------------------------
-    const int ncols = rows < NBO ? rows : NBO;  // the next panel's columns
-    PTA_HIP(hipEventRecord(cx->ev_f, sp));
-    if (rows > ncols) {
-      PTA_HIP(hipStreamWaitEvent(sb, cx->ev_f, 0));
-      const double *L21b = L21 + (int64_t)ncols * lda;
-      double *A22b = A22 + (int64_t)ncols * lda + ncols;
-      int rc = pta_dgemm_launch(1, rows - ncols, rows - ncols, nbo, -1.0, L21b, lda, 1, L21b, lda, 1.0, A22b, lda, 1, B, strideA, strideA, strideA,
-                                g_gemm_algo, sb);
-      if (rc != PTA_OK) return rc;
-    }
-    // ---- N(p) on the panel stream: the next panel's columns, after the previous bulk update that also touched them ----
-    if (bulk_pending) PTA_HIP(hipStreamWaitEvent(sp, cx->ev_b, 0));
-    {
-      int rc = pta_dgemm_launch(1, rows, ncols, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, g_gemm_algo, sp);
-      if (rc != PTA_OK) return rc;
-    }
-    if (rows > ncols) {
-      PTA_HIP(hipEventRecord(cx->ev_b, sb));
-      bulk_pending = true;
-    }
-  }
-  if (look) {  // join: the caller's stream continues after both
-    PTA_HIP(hipEventRecord(cx->ev_out_p, sp));
-    PTA_HIP(hipEventRecord(cx->ev_out_b, sb));
-    PTA_HIP(hipStreamWaitEvent(s, cx->ev_out_p, 0));
-    PTA_HIP(hipStreamWaitEvent(s, cx->ev_out_b, 0));
   }
   if (flags & PTA_POTRF_ZERO_UPPER) {
     hipLaunchKernelGGL(k_zero_upper, dim3(pta_cdiv(n, 256), n, B), dim3(256), 0, s, A, n, lda, strideA);

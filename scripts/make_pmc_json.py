@@ -8,12 +8,13 @@ from bench import SYNTH_SRC, TD_SRC, src_sha
 out_dir, R, n_toa, n_psr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 
 
-def sums(pass_dir, match):
-    """mean per dispatch of every counter, over the dispatches of kernels whose name contains `match`"""
+def sums(pass_dir, match, grid=None):
+    """mean per dispatch of every counter, over the dispatches of kernels whose name contains `match` (and, if given, whose
+    Grid_Size equals `grid`).  rocprofv3 reports one row per (dispatch, counter), already summed over the 8 XCDs."""
     acc, disp = collections.Counter(), set()
     for p in glob.glob(os.path.join(out_dir, pass_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(p)):
-            if match in r["Kernel_Name"]:
+            if match in r["Kernel_Name"] and (grid is None or int(r["Grid_Size"]) == grid):
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 disp.add((p, r["Dispatch_Id"]))
     n = max(len(disp), 1)
@@ -31,7 +32,8 @@ def avg_ms(match):
 
 
 res = {}
-CU, SIMD = 256, 4
+SIMD_PER_XCD = 128   # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (checked: value / kernel duration = 8 x ~2 GHz), so
+                     # GUI_ACTIVE x 128 SIMDs per XCD = SIMD-cycles of the whole chip during the dispatch
 # ---- fused synthesis kernel
 k = "k_engine_synth_mfma<false>"
 f, nf = sums("pmc_fetch", k)
@@ -45,14 +47,17 @@ if nf and nw:
     if na:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE"):
-            e["valu_busy"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (a["GRBM_GUI_ACTIVE"] * CU * SIMD) if a.get("SQ_ACTIVE_INST_VALU") else None
+            e["valu_busy"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD) if a.get("SQ_ACTIVE_INST_VALU") else None
+            e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
     res[k] = e
-# ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x CUs x SIMDs)
-for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov", "k_trsm_mfma"):
+# ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches
+for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov", "k_trsm_mfma", "k_mb_mfma"):
     m, nm = sums("pmc_mfma", k)
     ms, nt = avg_ms(k)
     if nm and m.get("GRBM_GUI_ACTIVE"):
-        res[k] = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * CU * SIMD),
+        res[k] = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD),
+                  "executed_TFLOPs": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 64 * 2048 / (ms * 1e-3) / 1e12 if ms else None,
+                  "engine_clock_GHz_under_pmc": m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None,
                   "mfma_busy_cycles_per_dispatch": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active_cycles_per_dispatch": m["GRBM_GUI_ACTIVE"],
                   "insts_valu_per_dispatch": m.get("SQ_INSTS_VALU"), "avg_launch_ms_rocprof": ms, "dispatches": nm, "src_sha": src_sha(*TD_SRC),
                   "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
