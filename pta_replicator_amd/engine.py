@@ -602,6 +602,54 @@ class ReplicaEngine(TimeDomainMixin):
             psr.update_residuals()
         return row
 
+    def to_enterprise(self, rows, subtract_mean=True):
+        """enterprise-style pulsar objects for realisations already generated: ``rows`` is a [R, n_toa] tensor / array (e.g. the
+        output of generate() or generate_td()); returns R lists of P ``ArrayEnterprisePulsar`` whose ``residuals`` are the injected
+        delays with the weighted mean removed (what PINT's Residuals would report for an idealised pulsar) -
+        the hand-off of SURVEY.md §8f rank 4 for whole ensembles, without a par/tim round trip."""
+        from .simulate import ArrayEnterprisePulsar
+        arr = rows.detach().cpu().numpy() if hasattr(rows, "detach") else np.asarray(rows)
+        if arr.ndim == 1:
+            arr = arr[None, :]
+        out = []
+        for row in arr:
+            psrs = []
+            for a, psr in enumerate(self.psrs):
+                x = row[self.off[a]:self.off[a + 1]]
+                if subtract_mean:
+                    w = 1.0 / np.asarray(psr.toas.get_errors().to("us").value, dtype=np.float64) ** 2
+                    x = x - np.sum(x * w) / np.sum(w)
+                psrs.append(ArrayEnterprisePulsar.from_simulated(psr, residuals_s=x))
+            out.append(psrs)
+        return out
+
+    def write_tim_ensemble(self, rows, outdir, r0=0):
+        """Batched counterpart of SimulatedPulsar.write_partim (simulate.py:71-77) for array-backed pulsars: one directory
+        ``real_<r>/`` per realisation with a Tempo2 tim file per pulsar whose TOAs are the ideal TOAs shifted by the injected
+        delay - without touching the pulsar objects (no per-realisation adjust_TOAs / residual rebuild)."""
+        import os
+        from .simulate import ArrayTOAs
+        arr = rows.detach().cpu().numpy() if hasattr(rows, "detach") else np.asarray(rows)
+        if arr.ndim == 1:
+            arr = arr[None, :]
+        paths = []
+        for k, row in enumerate(arr):
+            d = os.path.join(outdir, f"real_{r0 + k:06d}")
+            os.makedirs(d, exist_ok=True)
+            for a, psr in enumerate(self.psrs):
+                if not isinstance(psr.toas, ArrayTOAs):
+                    raise NotImplementedError("write_tim_ensemble needs array-backed pulsars (PINT-backed: use inject() + write_partim)")
+                mjd = psr.toas.mjd0_ld + (row[self.off[a]:self.off[a + 1]] / 86400.0).astype(np.longdouble)
+                path = os.path.join(d, f"{psr.name}.tim")
+                with open(path, "w") as fh:
+                    fh.write("FORMAT 1\n")
+                    for i in range(len(mjd)):
+                        fl = " ".join(f"-{kk} {v}" for kk, v in psr.toas.flags[i].items())
+                        fh.write(f" {psr.name} {psr.toas.freqs_mhz[i]:.8f} {np.format_float_positional(mjd[i], precision=19)} "
+                                 f"{psr.toas.errors_us[i]:.5f} AXIS {fl}\n")
+                paths.append(path)
+        return paths
+
     def split(self, arr):
         """per-pulsar views of an [..., n_toa] array."""
         return [arr[..., self.off[a]:self.off[a + 1]] for a in range(self.P)]

@@ -171,9 +171,63 @@ class SimulatedPulsar:
             self.added_signals_time[signal_name] = dt
 
     def to_enterprise(self, ephem="DE440"):
-        """enterprise PintPulsar (simulate.py:91-95); needs enterprise + PINT."""
+        """Hand-off to enterprise (simulate.py:91-95).  PINT-backed pulsars: the reference's own call,
+        ``enterprise.pulsar.Pulsar(toas, model, ephem=ephem, timing_package="pint")``.  Array-backed pulsars: an
+        ``ArrayEnterprisePulsar`` carrying the attribute surface enterprise's signal models read (no par/tim round trip)."""
+        if isinstance(self.toas, ArrayTOAs):
+            if self.residuals is None:
+                self.update_residuals()
+            return ArrayEnterprisePulsar.from_simulated(self)
         from enterprise.pulsar import Pulsar
         return Pulsar(self.toas, self.model, ephem=ephem, timing_package="pint")
+
+
+class ArrayEnterprisePulsar:
+    """The part of ``enterprise.pulsar.BasePulsar`` that enterprise's signal classes read, filled straight from arrays
+    (lets an analysis consume GPU-generated realisations without writing and re-reading par/tim files).
+
+    Attributes, in enterprise's units: ``name``; ``toas`` [s, MJD * 86400]; ``residuals`` [s]; ``toaerrs`` [s]; ``freqs`` [MHz];
+    ``flags`` (dict flag -> array of str, one entry per TOA, '' where a TOA lacks the flag); ``backend_flags`` (the 'f' flag, else
+    'group'/'be' as enterprise falls back); ``Mmat`` [N x 3] timing-model design matrix of an idealised pulsar (offset, t, t^2 -
+    the columns that absorb the mean and the spin-down a fit would remove); ``pos`` unit vector, ``theta`` / ``phi`` [rad];
+    ``pdist`` (1.0, 0.2) kpc as enterprise defaults it.  UNPINNED: enterprise is not installed here and the reference has no
+    test of its hand-off; the attribute list follows enterprise/pulsar.py."""
+
+    def __init__(self, name, mjd, residuals_s, toaerrs_us, freqs_mhz, flags, ra, dec):
+        order = np.argsort(np.asarray(mjd, dtype=np.float64), kind="mergesort")   # enterprise sorts TOAs by default (sort=True)
+        self.name = name
+        self._isort = order
+        self.toas = (np.asarray(mjd, dtype=np.float64) * 86400.0)[order]
+        self.stoas = self.toas.copy()
+        self.residuals = np.asarray(residuals_s, dtype=np.float64)[order]
+        self.toaerrs = (np.asarray(toaerrs_us, dtype=np.float64) * 1e-6)[order]
+        self.freqs = np.asarray(freqs_mhz, dtype=np.float64)[order]
+        keys = sorted({k for f in flags for k in f})
+        self.flags = {k: np.array([str(flags[i].get(k, "")) for i in order]) for k in keys}
+        for k in ("f", "group", "be"):
+            if k in self.flags:
+                self.backend_flags = self.flags[k]
+                break
+        else:
+            self.backend_flags = np.array([""] * len(order))
+        t = self.toas - self.toas.mean()
+        scale = max(float(np.max(np.abs(t))), 1.0)
+        self.Mmat = np.stack([np.ones_like(t), t / scale, (t / scale) ** 2], axis=1)
+        self.fitpars = ["Offset", "F0", "F1"]
+        self.theta, self.phi = float(np.pi / 2 - dec), float(ra)
+        self.pos = np.array([np.cos(ra) * np.cos(dec), np.sin(ra) * np.cos(dec), np.sin(dec)])
+        self.pdist = (1.0, 0.2)
+        self.dm = None
+
+    @classmethod
+    def from_simulated(cls, psr, residuals_s=None):
+        from ._position import ra_dec
+        ra, dec = ra_dec(psr, default=(0.0, 0.0))
+        res = psr.residuals.resids_value if residuals_s is None else residuals_s
+        return cls(psr.name, psr.toas.mjd0_ld.astype(np.float64), res, psr.toas.errors_us, psr.toas.freqs_mhz, psr.toas.flags, ra, dec)
+
+    def __repr__(self):
+        return f"ArrayEnterprisePulsar({self.name}, {len(self.toas)} TOAs)"
 
 
 # ----------------------------------------------------------------------------------------------

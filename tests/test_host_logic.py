@@ -262,3 +262,27 @@ def test_burst_transient_and_memory_injectors_match_the_reference():
         assert relrms(sig(p, "gw_memory"), z["gw_memory"][a]) < 1e-12
         with pytest.raises(ValueError):
             add_gw_memory(p, 3e-14, 0.7, 5.1, 0.9, 55500.0)          # same signal twice (simulate.py:85-86)
+
+
+def test_array_enterprise_pulsar_hand_off(tmp_path):
+    """to_enterprise() of an array-backed pulsar: enterprise's attribute surface, TOA-sorted, in enterprise's units; tim files
+    written from a delay vector read back to the shifted TOAs."""
+    from pta_replicator_amd.simulate import ArrayEnterprisePulsar, ArrayTOAs, SimulatedPulsar, make_ideal, read_tim
+    from pta_replicator_amd._compat import TimeDelta, u
+    rng = np.random.default_rng(4)
+    mjd = rng.uniform(53000, 54000, 50)                     # unsorted on purpose
+    flags = [{"f": "A" if i % 3 else "B", "pta": "NG"} for i in range(50)]
+    psr = SimulatedPulsar(toas=ArrayTOAs(mjd, rng.uniform(0.2, 1.0, 50), flags=flags), name="J1234+5678", loc={"RAJ": 6.0, "DECJ": 30.0})
+    make_ideal(psr)
+    dt = rng.standard_normal(50) * 1e-6
+    psr.update_added_signals("J1234+5678_test", {}, dt * u.s)
+    psr.toas.adjust_TOAs(TimeDelta((dt * u.s).to("day")))
+    psr.update_residuals()
+    ep = psr.to_enterprise()
+    assert isinstance(ep, ArrayEnterprisePulsar) and ep.name == "J1234+5678"
+    order = np.argsort(mjd, kind="mergesort")
+    assert np.all(np.diff(ep.toas) >= 0) and np.allclose(ep.toas, mjd[order] * 86400.0)
+    assert np.allclose(ep.residuals, psr.residuals.resids_value[order], rtol=0, atol=1e-18)
+    assert np.allclose(ep.toaerrs, psr.toas.errors_us[order] * 1e-6) and list(ep.backend_flags) == [flags[i]["f"] for i in order]
+    assert ep.Mmat.shape == (50, 3) and np.linalg.matrix_rank(ep.Mmat) == 3
+    assert abs(np.linalg.norm(ep.pos) - 1) < 1e-15 and abs(ep.theta - (np.pi / 2 - np.pi / 6)) < 1e-15 and abs(ep.phi - np.pi / 2) < 1e-15
