@@ -107,8 +107,12 @@ int pta_ecorr(const int32_t *epoch_of, const double *ecorr_epoch, int N, int E, 
 int pta_orf_hd(const double *locs, int P, double *orf, void *stream);
 
 /* basis[(k*P + a)*P + b], k = l*l + (m + l): spharmORFbasis.correlated_basis
- * (spharmORFbasis.py:385-434 and callees :14-382). lmax <= 8.                              */
-int pta_orf_basis(const double *locs, int P, int lmax, double *basis, void *stream);
+ * (spharmORFbasis.py:385-434 and callees :14-382). lmax <= 8.
+ * zeta_cos (device, may be NULL): zeta_cos[2*(a*P+b) + 0/1] = the pair's angular separation zeta and cos(zeta) exactly as the
+ * reference computes them (calczeta :14-35, np.cos at :166; host libm).  The l >= 3 sums are ill-conditioned in cos(zeta)
+ * (~1e5-1e6), so 1-2 ulp between device and libm acos/cos were a 7e-10 parity error; with the host's values it is the sums'
+ * own rounding only.  NULL = both are derived on the device.                                   */
+int pta_orf_basis(const double *locs, const double *zeta_cos, int P, int lmax, double *basis, void *stream);
 
 /* orf = 2 * sum_k clm[k] * basis[k]  (red_noise.py:225-226). clm is a device array.        */
 int pta_orf_combine(const double *basis, const double *clm, int nbasis, int P, double *orf, void *stream);
@@ -221,13 +225,15 @@ int pta_cgw(const double *mjd, int N, const double *par_host, double *out, int a
 
 /* Catalogue of N_cw continuous-wave sources for one pulsar (add_catalog_of_cws and its numba kernels,
  * deterministic.py:188-561): out[i] (+)= sum_c waveform_c(mjd[i]), NaN terms dropped (:435,:556).
- * sources[c*8 + 0..7] = gwtheta, gwphi, mc [Msun], dist [Mpc], fgw [Hz], phase0, psi, inc (device);
- * phat_host[3] the pulsar unit vector; unit_consts_host = {SOLAR2S, KPC2S, MPC2S} (constants.py:6-8);
- * mode 0 evolve / 1 phase_approx / 2 monochromatic.  Workspaces sized by pta_cw_catalog_workspace (doubles). */
-int pta_cw_catalog_workspace(int N, int ncw, int64_t *par_doubles, int64_t *partial_doubles, int *nchunk);
-int pta_cw_catalog(const double *mjd, int N, const double *sources, int ncw, const double *phat_host,
-                   const double *unit_consts_host, double pdist_kpc, int use_pphase, double pphase, int psr_term, int mode,
-                   double tref, double *par_ws, double *partial_ws, double *out, int accumulate, void *stream);
+ * par[c*PTA_CW_NPAR + 0..] (device) = the per-source scalars the reference computes at the top of its loop body (:331-383),
+ * evaluated on the HOST (pta_replicator_amd.deterministic.cw_source_params) so that they are bit-identical to the reference's:
+ *  0 w0  1 phase0(orbital)  2 w0^(-5/3)  3 fac1  4 fac2  5 fac3  6 incfac1  7 incfac2  8 cos2psi  9 sin2psi  10 fplus  11 fcross
+ *  12 pd*(1-cosMu) [s]  13 omega_p (phase_approx, :395)  14 phase0 + fac2*(w053 - omega_p^(-5/3)) (phase_approx, :399)  15 unused
+ * mode 0 evolve / 1 phase_approx / 2 monochromatic.  partial_ws sized by pta_cw_catalog_workspace (doubles).             */
+#define PTA_CW_NPAR 16
+int pta_cw_catalog_workspace(int N, int ncw, int64_t *partial_doubles, int *nchunk);
+int pta_cw_catalog(const double *mjd, int N, const double *par, int ncw, int psr_term, int mode, double tref,
+                   double *partial_ws, double *out, int accumulate, void *stream);
 
 /* ---------------------------------------------------------------- fused engine ----- */
 /* One pass that writes R whole-array realisations: out[r, i] = RN + GWB + WN + ECORR + det,

@@ -502,9 +502,18 @@ def gwb_dt(grid, M, w, C, toa_s_list):
 # ----------------------------------------------------------------------------------------
 # continuous wave  (deterministic.py:13-185)
 # ----------------------------------------------------------------------------------------
+def cr_pow(x, y):
+    """x ** y rounded ONCE from an 80-bit evaluation: the correctly rounded float64 power (up to x87 double rounding, 2^-11 of
+    the cases).  NumPy's own float64 ``**`` is not correctly rounded - its array loops are SIMD kernels with errors of a few
+    ulp, its scalar path is libm - which matters where the reference subtracts two nearly equal powers (deterministic.py:118)."""
+    return np.asarray(np.power(np.asarray(x, dtype=np.longdouble), np.longdouble(np.float64(y))), dtype=np.float64)
+
+
 def cgw_dt(mjd, ptheta, pphi, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, pdist=1.0, pphase=None,
-           psrTerm=True, evolve=True, phase_approx=False, tref=0):
-    """CW residual on float64 MJDs for a pulsar at (ptheta colatitude, pphi) (deterministic.py:50-163)."""
+           psrTerm=True, evolve=True, phase_approx=False, tref=0, power=np.power):
+    """CW residual on float64 MJDs for a pulsar at (ptheta colatitude, pphi) (deterministic.py:50-163).  ``power`` is the
+    float64 pow used for the per-TOA frequency / phase evolution (default: NumPy's, like the reference; ``cr_pow`` = correctly
+    rounded) - every other operation is IEEE basic arithmetic and identical on any machine."""
     mc = mc * SOLAR2S
     dist = dist * MPC2S
     w0 = np.pi * fgw
@@ -528,10 +537,10 @@ def cgw_dt(mjd, ptheta, pphi, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, p
     pd = pd * KPC2S
     tp = toas - pd * (1 - cosMu)
     if evolve:
-        omega = w0 * (1 - fac1 * toas) ** (-3 / 8)
-        omega_p = w0 * (1 - fac1 * tp) ** (-3 / 8)
-        phase = phase0 + fac2 * (w053 - omega ** (-5 / 3))
-        phase_p = phase0 + fac2 * (w053 - omega_p ** (-5 / 3))
+        omega = w0 * power(1 - fac1 * toas, -3 / 8)
+        omega_p = w0 * power(1 - fac1 * tp, -3 / 8)
+        phase = phase0 + fac2 * (w053 - power(omega, -5 / 3))
+        phase_p = phase0 + fac2 * (w053 - power(omega_p, -5 / 3))
     elif phase_approx:
         omega = w0
         omega_p = w0 * (1 + fac1 * pd * (1 - cosMu)) ** (-3 / 8)
@@ -556,7 +565,7 @@ def cgw_dt(mjd, ptheta, pphi, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, p
 
 
 def cw_catalog_dt(mjd, ptheta, pphi, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_list, phase0_list, psi_list, inc_list,
-                  pdist=1.0, pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=0):
+                  pdist=1.0, pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=0, power=np.power):
     """sum over sources of the single-source waveform with NaN -> 0, in catalogue order (add_catalog_of_cws and
     loop_over_CWs, deterministic.py:188-318, :443-561; the parallel variant :321-440 sums the same terms)."""
     res = np.zeros(len(mjd))
@@ -564,7 +573,7 @@ def cw_catalog_dt(mjd, ptheta, pphi, gwtheta_list, gwphi_list, mc_list, dist_lis
         with np.errstate(invalid="ignore"):
             rrr = cgw_dt(mjd, ptheta, pphi, gwtheta_list[i], gwphi_list[i], mc_list[i], dist_list[i], fgw_list[i], phase0_list[i],
                          psi_list[i], inc_list[i], pdist=pdist, pphase=pphase, psrTerm=psrTerm, evolve=evolve,
-                         phase_approx=phase_approx, tref=tref)
+                         phase_approx=phase_approx, tref=tref, power=power)
         res += np.where(np.isnan(rrr), 0.0, rrr)
     return res
 

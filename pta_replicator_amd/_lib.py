@@ -72,7 +72,7 @@ _SIGNATURES = {
     "pta_quantize_epochs": (c_int, [_P, c_int, c_double, _P, _P, _P, POINTER(c_int)]),
     "pta_ecorr": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_orf_hd": (c_int, [_P, c_int, _P, _P]),
-    "pta_orf_basis": (c_int, [_P, c_int, c_int, _P, _P]),
+    "pta_orf_basis": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_potrf_batched": (c_int, [_P, c_int, c_int, _P, _P]),
     "pta_potrf_batched_ex": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P]),
@@ -89,8 +89,8 @@ _SIGNATURES = {
     "pta_gwb_weights": (c_int, [_P, c_int, _P, _P, c_int, _P, _P]),
     "pta_gwb_interp": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_double, _P, c_int64, c_int, _P]),
     "pta_cgw": (c_int, [_P, c_int, _P, _P, c_int, _P]),
-    "pta_cw_catalog_workspace": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
-    "pta_cw_catalog": (c_int, [_P, c_int, _P, c_int, _P, _P, c_double, c_int, c_double, c_int, c_int, c_double, _P, _P, _P, c_int, _P]),
+    "pta_cw_catalog_workspace": (c_int, [c_int, c_int, POINTER(c_int64), POINTER(c_int)]),
+    "pta_cw_catalog": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_double, _P, _P, c_int, _P]),
     "pta_engine_rn_coef": (c_int, [c_uint64, c_uint64, c_int, c_int, c_int, _P, _P, c_int, _P]),
     "pta_engine_generate": (c_int, [POINTER(EnginePlan), POINTER(EngineTables), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_engine_synth": (c_int, [POINTER(EnginePlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),

@@ -1,53 +1,19 @@
 // Catalogue of continuous-wave sources: sum over N_cw SMBHBs of the add_cgw waveform for one pulsar.
 // Replaces add_catalog_of_cws and its two numba kernels loop_over_CWs_parallel / loop_over_CWs
 // (deterministic.py:188-318, :321-440, :443-561): the reference's own "make it fast" code path.
-//   k_cw_source_params : the per-source scalars of deterministic.py:331-383 (unit conversion, antenna patterns, chirp factors)
+//   (the per-source scalars of deterministic.py:331-383 - unit conversion, antenna patterns, chirp factors, pd (1 - cos mu) - come
+//    from the host, pta_replicator_amd.deterministic.cw_source_params: one ulp of cos mu is up to 4e-11 rad of pulsar-term phase)
 //   k_cw_catalog       : one thread per TOA, sources walked through the scalar unit; NaN contributions (binaries that
 //                        already merged) are dropped as in :435,:556; per-chunk partial sums
 //   k_cw_reduce        : fixed-order sum of the partials (deterministic, unlike atomics)
 #include "pta_common.h"
 
-#define CW_NPAR 16
+#define CW_NPAR PTA_CW_NPAR
 
 struct pta_cw_opts {
-  double phat[3];
-  double pdist_kpc, pphase, tref;
-  double solar2s, kpc2s, mpc2s;  // constants.py:6-8, handed over by the host so that they are bit-identical
-  int use_pphase, psr_term, mode;  // mode 0 evolve, 1 phase_approx, 2 monochromatic
+  double tref;
+  int psr_term, mode;  // mode 0 evolve, 1 phase_approx, 2 monochromatic
 };
-
-__global__ void k_cw_source_params(const double *__restrict__ src, int ncw, pta_cw_opts o, double *__restrict__ par) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= ncw) return;
-  const double SOLAR2S = o.solar2s, KPC2S = o.kpc2s, MPC2S = o.mpc2s;
-  const double *s = src + (int64_t)i * 8;
-  double gwtheta = s[0], gwphi = s[1], mc = s[2] * SOLAR2S, dist = s[3] * MPC2S, fgw = s[4], phase0 = s[5] / 2, psi = s[6], inc = s[7];
-  double w0 = 3.141592653589793 * fgw;
-  double w053 = pow(w0, -5.0 / 3.0);
-  double cgt = cos(gwtheta), cgp = cos(gwphi), sgt = sin(gwtheta), sgp = sin(gwphi);
-  double s2p = sin(2 * psi), c2p = cos(2 * psi);
-  double incfac1 = 0.5 * (3 + cos(2 * inc)), incfac2 = 2 * cos(inc);
-  double m[3] = {sgp, -cgp, 0.0}, n[3] = {-cgt * cgp, -cgt * sgp, sgt}, om[3] = {-sgt * cgp, -sgt * sgp, -cgt};
-  double mc53 = pow(mc, 5.0 / 3.0);
-  double fac1 = 256.0 / 5.0 * mc53 * pow(w0, 8.0 / 3.0);
-  double fac2 = 1.0 / 32.0 / mc53;
-  double fac3 = mc53 / dist;
-  double mp = m[0] * o.phat[0] + m[1] * o.phat[1] + m[2] * o.phat[2];
-  double np_ = n[0] * o.phat[0] + n[1] * o.phat[1] + n[2] * o.phat[2];
-  double op = om[0] * o.phat[0] + om[1] * o.phat[1] + om[2] * o.phat[2];
-  double fplus = 0.5 * (mp * mp - np_ * np_) / (1 + op);
-  double fcross = (mp * np_) / (1 + op);
-  double cosMu = -op;
-  double pd = o.use_pphase ? o.pphase / (2 * 3.141592653589793 * fgw * (1 - cosMu)) / KPC2S : o.pdist_kpc;
-  pd = pd * KPC2S;
-  double *p = par + (int64_t)i * CW_NPAR;
-  p[0] = w0; p[1] = phase0; p[2] = w053; p[3] = fac1; p[4] = fac2; p[5] = fac3; p[6] = incfac1; p[7] = incfac2;
-  p[8] = c2p; p[9] = s2p; p[10] = fplus; p[11] = fcross; p[12] = pd * (1 - cosMu);
-  double omega_p = w0 * pow(1 + fac1 * pd * (1 - cosMu), -3.0 / 8.0);
-  p[13] = omega_p;                                        // phase_approx (:395)
-  p[14] = phase0 + fac2 * (w053 - pow(omega_p, -5.0 / 3.0));  // phase_approx (:399)
-  p[15] = 0.0;
-}
 
 #define CW_TILE 256
 __global__ __launch_bounds__(CW_TILE) void k_cw_catalog(const double *__restrict__ mjd, int N, const double *__restrict__ par, int ncw,
@@ -100,36 +66,30 @@ __global__ void k_cw_reduce(const double *__restrict__ partial, int nchunk, int 
   out[i] = accumulate ? out[i] + s : s;
 }
 
-extern "C" int pta_cw_catalog_workspace(int N, int ncw, int64_t *par_doubles, int64_t *partial_doubles, int *nchunk_out) {
-  PTA_REQUIRE(N > 0 && ncw > 0 && par_doubles && partial_doubles && nchunk_out, PTA_E_ARG, "pta_cw_catalog_workspace: bad argument");
+extern "C" int pta_cw_catalog_workspace(int N, int ncw, int64_t *partial_doubles, int *nchunk_out) {
+  PTA_REQUIRE(N > 0 && ncw > 0 && partial_doubles && nchunk_out, PTA_E_ARG, "pta_cw_catalog_workspace: bad argument");
   int tiles = (N + CW_TILE - 1) / CW_TILE;
   int want = (4096 + tiles - 1) / tiles;  // ~16 workgroups per CU in flight
   int nchunk = want < 1 ? 1 : (want > ncw ? ncw : want);
   if (nchunk > 65535) nchunk = 65535;
   *nchunk_out = nchunk;
-  *par_doubles = (int64_t)ncw * CW_NPAR;
   *partial_doubles = (int64_t)nchunk * N;
   return PTA_OK;
 }
 
-extern "C" int pta_cw_catalog(const double *mjd, int N, const double *sources, int ncw, const double *phat_host,
-                              const double *unit_consts_host, double pdist_kpc, int use_pphase, double pphase, int psr_term, int mode,
-                              double tref, double *par_ws, double *partial_ws, double *out, int accumulate, void *stream) {
-  PTA_REQUIRE(mjd && sources && phat_host && unit_consts_host && par_ws && partial_ws && out, PTA_E_ARG, "pta_cw_catalog: NULL argument");
+extern "C" int pta_cw_catalog(const double *mjd, int N, const double *par, int ncw, int psr_term, int mode, double tref,
+                              double *partial_ws, double *out, int accumulate, void *stream) {
+  PTA_REQUIRE(mjd && par && partial_ws && out, PTA_E_ARG, "pta_cw_catalog: NULL argument");
   PTA_REQUIRE(N > 0 && ncw > 0 && mode >= 0 && mode <= 2, PTA_E_ARG, "pta_cw_catalog: N=%d ncw=%d mode=%d", N, ncw, mode);
   pta_cw_opts o;
-  for (int k = 0; k < 3; ++k) o.phat[k] = phat_host[k];
-  o.solar2s = unit_consts_host[0]; o.kpc2s = unit_consts_host[1]; o.mpc2s = unit_consts_host[2];
-  o.pdist_kpc = pdist_kpc; o.pphase = pphase; o.tref = tref; o.use_pphase = use_pphase; o.psr_term = psr_term; o.mode = mode;
-  int64_t a, b;
+  o.tref = tref; o.psr_term = psr_term; o.mode = mode;
+  int64_t b;
   int nchunk;
-  pta_cw_catalog_workspace(N, ncw, &a, &b, &nchunk);
+  pta_cw_catalog_workspace(N, ncw, &b, &nchunk);
   int chunk = (ncw + nchunk - 1) / nchunk;
   nchunk = (ncw + chunk - 1) / chunk;
   hipStream_t s = pta_stream(stream);
-  hipLaunchKernelGGL(k_cw_source_params, dim3(pta_cdiv(ncw, 256)), dim3(256), 0, s, sources, ncw, o, par_ws);
-  PTA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_cw_catalog, dim3(pta_cdiv(N, CW_TILE), nchunk), dim3(CW_TILE), 0, s, mjd, N, par_ws, ncw, chunk, o, partial_ws);
+  hipLaunchKernelGGL(k_cw_catalog, dim3(pta_cdiv(N, CW_TILE), nchunk), dim3(CW_TILE), 0, s, mjd, N, par, ncw, chunk, o, partial_ws);
   PTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_cw_reduce, dim3(pta_cdiv(N, 256)), dim3(256), 0, s, partial_ws, nchunk, N, out, accumulate);
   PTA_LAUNCH_CHECK();

@@ -25,10 +25,41 @@ PTA_HD double pta_fact(int n) {
   return t[n];
 }
 
-// x**p, integer p >= 0.  Goes through pow() like NumPy's float64 ** int does: the finite sums below
-// cancel heavily for l >= 3 near zeta -> 0 or pi (condition ~1e6), so repeated multiplication instead of a
-// (nearly) correctly rounded pow shows up at the 1e-10 level in the reference-vs-device comparison.
-PTA_HD double pta_ipow(double x, int p) { return pow(x, (double)p); }
+// x**p, integer p >= 0, rounded ONCE: the product chain is carried in double-double (error-free products through fma), so
+// the result is the correctly rounded power - what NumPy's float64 ** int (libm pow, < 0.52 ulp) returns in all but a
+// vanishing fraction of cases.  The finite sums below cancel heavily for l >= 3 (condition ~1e5-1e6): the device library's
+// pow() (1-2 ulp) left a 7e-10 parity error at l = 4 against 1e-11 of rounding noise in the reference itself.
+PTA_HD double pta_ipow(double x, int p) {
+  double hi = 1.0, lo = 0.0;
+  for (int i = 0; i < p; ++i) {
+    const double ph = hi * x;
+    const double pl = fma(hi, x, -ph) + lo * x;  // exact low part of hi * x, plus the carried low part
+    const double s = ph + pl;
+    lo = pl - (s - ph);
+    hi = s;
+  }
+  return hi;
+}
+
+// x**(n2 / 2) for integer n2 >= 0 and x >= 0, rounded once: integer part as above, an odd n2 adds a double-double sqrt(x).
+PTA_HD double pta_pow_half(double x, int n2) {
+  double hi = 1.0, lo = 0.0;
+  for (int i = 0; i < (n2 >> 1); ++i) {
+    const double ph = hi * x;
+    const double pl = fma(hi, x, -ph) + lo * x;
+    const double s = ph + pl;
+    lo = pl - (s - ph);
+    hi = s;
+  }
+  if (n2 & 1) {
+    const double r = sqrt(x);                                   // correctly rounded (IEEE)
+    const double rl = (r > 0.0) ? fma(-r, r, x) / (2.0 * r) : 0.0;  // sqrt(x) = r + rl to ~2^-100
+    const double ph = hi * r;
+    const double pl = fma(hi, r, -ph) + (hi * rl + lo * r);
+    return ph + pl;
+  }
+  return hi;
+}
 
 PTA_HD double pta_pow2i(int e) { return ldexp(1.0, e); }
 PTA_HD double pta_sgn(int n) { return (n & 1) ? -1.0 : 1.0; }
@@ -72,10 +103,11 @@ PTA_HD double pta_Fplus01(int qq, int mm, int ll, double c) {  // spharmORFbasis
   return tot;
 }
 
-// computational-frame Gamma_lm, zeta in (0, pi]   (spharmORFbasis.py:164-248)
-PTA_HD double pta_arbORF(int mm, int ll, double zeta) {
+// computational-frame Gamma_lm, zeta in (0, pi]   (spharmORFbasis.py:164-248).  c = cos(zeta) is an INPUT: the finite sums
+// below cancel heavily for l >= 3 (condition ~1e5-1e6 in c), so the caller may supply the very c the reference computes
+// (host libm) instead of the device's cos(acos(.)) - the 1-2 ulp between them was the whole l >= 3 parity error.
+PTA_HD double pta_arbORF(int mm, int ll, double zeta, double c) {
   const double NORM = 3.0 / (8.0 * PTA_PI);
-  double c = cos(zeta);
   double pre = sqrt((2.0 * ll + 1.0) * PTA_PI);
   if (mm == 0) {
     double body = -(1.0 + c) * pta_Fminus00(0, 0, ll, c);
@@ -87,8 +119,8 @@ PTA_HD double pta_arbORF(int mm, int ll, double zeta) {
     return NORM * 0.5 * pre * body;
   }
   if (mm == 1) {
-    double a = pow(1.0 + c, 1.5) / pow(1.0 - c, 0.5);
-    double b = pow(1.0 - c, 1.5) / pow(1.0 + c, 0.5);
+    double a = pta_pow_half(1.0 + c, 3) / pta_pow_half(1.0 - c, 1);
+    double b = pta_pow_half(1.0 - c, 3) / pta_pow_half(1.0 + c, 1);
     double body = -a * pta_Fminus00(1, 1, ll, c) - b * pta_Fplus01(2, 1, ll, c);
     if (ll == 1 || ll == 2) {
       double delta = (ll == 1) ? 2.0 * sin(zeta) / 3.0 : -2.0 * sin(zeta) / 5.0;
@@ -96,28 +128,28 @@ PTA_HD double pta_arbORF(int mm, int ll, double zeta) {
     }
     return NORM * 0.25 * pre * sqrt(pta_fact(ll - 1) / pta_fact(ll + 1)) * body;
   }
-  double h = mm / 2.0;
-  double body = (pow(1.0 + c, h + 1.0) / pow(1.0 - c, h)) * pta_Fminus00(mm, mm, ll, c) -
-                (pow(1.0 + c, h) / pow(1.0 - c, h - 1.0)) * pta_Fminus01(mm - 1, mm, ll, c) +
-                (pow(1.0 - c, h + 1.0) / pow(1.0 + c, h)) * pta_Fplus01(mm + 1, mm, ll, c) -
-                (pow(1.0 - c, h) / pow(1.0 + c, h - 1.0)) * pta_Fplus00(mm, mm, ll, c);
+  // exponents h + 1, h, h - 1 with h = m / 2: half-integers, evaluated as x^(n2/2) with n2 = m + 2, m, m - 2
+  double body = (pta_pow_half(1.0 + c, mm + 2) / pta_pow_half(1.0 - c, mm)) * pta_Fminus00(mm, mm, ll, c) -
+                (pta_pow_half(1.0 + c, mm) / pta_pow_half(1.0 - c, mm - 2)) * pta_Fminus01(mm - 1, mm, ll, c) +
+                (pta_pow_half(1.0 - c, mm + 2) / pta_pow_half(1.0 + c, mm)) * pta_Fplus01(mm + 1, mm, ll, c) -
+                (pta_pow_half(1.0 - c, mm) / pta_pow_half(1.0 + c, mm - 2)) * pta_Fplus00(mm, mm, ll, c);
   return -NORM * 0.25 * pre * sqrt(pta_fact(ll - mm) / pta_fact(ll + mm)) * body;
 }
 
 // zeta == 0 closed forms (pulsar-term doubling) and zeta == pi special cases (spharmORFbasis.py:309-344)
-PTA_HD double pta_compframe_orf(int mm, int ll, double zeta) {
+PTA_HD double pta_compframe_orf(int mm, int ll, double zeta, double c) {
   const double NORM = 3.0 / (8.0 * PTA_PI);
   if (zeta == 0.0) {
-    if (ll == 0) return 2.0 * NORM * 0.25 * sqrt(PTA_PI * 4.0) * (1.0 + (cos(zeta) / 3.0));
-    if (ll == 1 && mm == 0) return -2.0 * 0.5 * NORM * sqrt(PTA_PI / 3.0) * (1.0 + cos(zeta));
-    if (ll == 2 && mm == 0) return 2.0 * 0.25 * NORM * (4.0 / 3.0) * sqrt(PTA_PI / 5.0) * cos(zeta);
+    if (ll == 0) return 2.0 * NORM * 0.25 * sqrt(PTA_PI * 4.0) * (1.0 + (c / 3.0));
+    if (ll == 1 && mm == 0) return -2.0 * 0.5 * NORM * sqrt(PTA_PI / 3.0) * (1.0 + c);
+    if (ll == 2 && mm == 0) return 2.0 * 0.25 * NORM * (4.0 / 3.0) * sqrt(PTA_PI / 5.0) * c;
     return 0.0;
   }
   if (zeta == PTA_PI) {
     if (ll > 2 || ((ll == 1 || ll == 2) && mm != 0)) return 0.0;
-    return pta_arbORF(mm, ll, zeta);
+    return pta_arbORF(mm, ll, zeta, c);
   }
-  return pta_arbORF(mm, ll, zeta);
+  return pta_arbORF(mm, ll, zeta, c);
 }
 
 // terminating Gauss series 2F1(a,b;c;z), a = m-l <= 0 and b = -k-l <= 0 integers (what
@@ -161,11 +193,13 @@ PTA_HD double pta_third_euler(double phi1, double phi2, double th1, double th2) 
 
 // All 2l+1 real-form cosmic-frame values for one pair and one l; out[m+l], m = -l..l
 // (correlated_basis inner body, spharmORFbasis.py:400-432).
-PTA_HD void pta_orf_pair_l(int l, double phi1, double phi2, double th1, double th2, double *out) {
-  double zeta = pta_calczeta(phi1, phi2, th1, th2);
+// zc = {zeta, cos(zeta)} of the pair as the reference computes them (host), or NULL to derive both here.
+PTA_HD void pta_orf_pair_l(int l, double phi1, double phi2, double th1, double th2, const double *zc, double *out) {
+  double zeta = zc ? zc[0] : pta_calczeta(phi1, phi2, th1, th2);
+  double cz = zc ? zc[1] : cos(zeta);
   double gam[2 * PTA_ORF_LMAX + 1];
   for (int mm = 0; mm <= l; ++mm) {
-    double v = pta_compframe_orf(mm, l, zeta);
+    double v = pta_compframe_orf(mm, l, zeta, cz);
     gam[l + mm] = v;
     gam[l - mm] = pta_sgn(mm) * v;  // Gamma_{l,-m} = (-1)^m Gamma_{lm} in the computational frame
   }

@@ -22,13 +22,13 @@ extern "C" int pta_orf_hd(const double *locs, int P, double *orf, void *stream) 
 
 // one thread per (a <= b, l): all 2l+1 real-form values, mirrored into both triangles
 // (correlated_basis, spharmORFbasis.py:385-434)
-__global__ void k_orf_basis(const double *__restrict__ locs, int P, double *__restrict__ basis) {
+__global__ void k_orf_basis(const double *__restrict__ locs, const double *__restrict__ zc, int P, double *__restrict__ basis) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   int a = blockIdx.y;
   int l = blockIdx.z;
   if (b >= P || b < a) return;
   double v[2 * PTA_ORF_LMAX + 1];
-  pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], v);
+  pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], zc ? zc + 2 * ((int64_t)a * P + b) : nullptr, v);
   for (int mi = 0; mi <= 2 * l; ++mi) {
     int64_t k = (int64_t)l * l + mi;
     basis[(k * P + a) * P + b] = v[mi];
@@ -36,11 +36,11 @@ __global__ void k_orf_basis(const double *__restrict__ locs, int P, double *__re
   }
 }
 
-extern "C" int pta_orf_basis(const double *locs, int P, int lmax, double *basis, void *stream) {
+extern "C" int pta_orf_basis(const double *locs, const double *zeta_cos, int P, int lmax, double *basis, void *stream) {
   PTA_REQUIRE(locs && basis, PTA_E_ARG, "pta_orf_basis: NULL argument");
   PTA_REQUIRE(P > 0 && P <= 65535, PTA_E_ARG, "pta_orf_basis: P=%d", P);
   PTA_REQUIRE(lmax >= 0 && lmax <= PTA_ORF_LMAX, PTA_E_ARG, "pta_orf_basis: lmax=%d unsupported (0..%d)", lmax, PTA_ORF_LMAX);
-  hipLaunchKernelGGL(k_orf_basis, dim3(pta_cdiv(P, 64), P, lmax + 1), dim3(64), 0, pta_stream(stream), locs, P, basis);
+  hipLaunchKernelGGL(k_orf_basis, dim3(pta_cdiv(P, 64), P, lmax + 1), dim3(64), 0, pta_stream(stream), locs, zeta_cos, P, basis);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

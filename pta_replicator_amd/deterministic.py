@@ -91,6 +91,68 @@ def add_cgw(psr, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, pdist=1.0, pph
     psr.update_residuals()
 
 
+CW_NPAR = 16              # PTA_CW_NPAR
+CW_SCALAR_LOOP_MAX = 20000  # up to this many sources the per-source scalars are evaluated one source at a time (see below)
+
+
+def cw_source_params(lists, phat, pdist=1.0, pphase=None):
+    """The realisation- and TOA-independent scalars of every source of a CW catalogue, as deterministic.py:331-383 computes
+    them at the top of its numba loops: [ncw, 16] = w0, orbital phase0, w0^(-5/3), fac1, fac2, fac3, incfac1, incfac2, cos 2psi,
+    sin 2psi, F+, Fx, pd (1 - cos mu) [s], and for phase_approx omega_p and its phase offset (:395,:399).
+
+    Computed on the HOST with NumPy, like add_cgw's (cgw_parameters): the pulsar-term phase is omega * pd * (1 - cos mu) with
+    pd ~ 1e11 s, so one ulp of cos mu moves a fast binary's phase by up to 4e-11 rad - device sin / cos of the source angles
+    (1-2 ulp) were the largest parity error of the catalogue.  Up to CW_SCALAR_LOOP_MAX sources they are evaluated one source
+    at a time on NumPy float64 SCALARS - the code path the reference's loop body takes, C libm underneath - so they are
+    bit-identical to the reference's; larger catalogues use array expressions (NumPy's SIMD loops can differ from libm by an
+    ulp)."""
+    gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc = lists
+    ncw = len(mc)
+    par = np.zeros((ncw, CW_NPAR))
+    if ncw <= CW_SCALAR_LOOP_MAX:
+        for i in range(ncw):
+            mci, di = mc[i] * SOLAR2S, dist[i] * MPC2S
+            w0 = np.pi * fgw[i]
+            w053 = w0 ** (-5 / 3)
+            cgt, cgp, sgt, sgp = np.cos(gwtheta[i]), np.cos(gwphi[i]), np.sin(gwtheta[i]), np.sin(gwphi[i])
+            m = np.array([sgp, -cgp, 0.0])
+            nn = np.array([-cgt * cgp, -cgt * sgp, sgt])
+            om = np.array([-sgt * cgp, -sgt * sgp, -cgt])
+            fac1 = 256 / 5 * mci ** (5 / 3) * w0 ** (8 / 3)
+            fac2 = 1 / 32 / mci ** (5 / 3)
+            fac3 = mci ** (5 / 3) / di
+            fplus = 0.5 * (np.dot(m, phat) ** 2 - np.dot(nn, phat) ** 2) / (1 + np.dot(om, phat))
+            fcross = (np.dot(m, phat) * np.dot(nn, phat)) / (1 + np.dot(om, phat))
+            cosMu = -np.dot(om, phat)
+            pd = pphase / (2 * np.pi * fgw[i] * (1 - cosMu)) / KPC2S if pphase is not None else pdist
+            pd = pd * KPC2S
+            omega_p = w0 * (1 + fac1 * pd * (1 - cosMu)) ** (-3 / 8)
+            with np.errstate(all="ignore"):
+                par[i] = (w0, phase0[i] / 2, w053, fac1, fac2, fac3, 0.5 * (3 + np.cos(2 * inc[i])), 2 * np.cos(inc[i]), np.cos(2 * psi[i]),
+                          np.sin(2 * psi[i]), fplus, fcross, pd * (1 - cosMu), omega_p, phase0[i] / 2 + fac2 * (w053 - omega_p ** (-5 / 3)), 0.0)
+        return par
+    with np.errstate(all="ignore"):
+        mcs, ds = mc * SOLAR2S, dist * MPC2S
+        w0 = np.pi * fgw
+        w053 = w0 ** (-5 / 3)
+        cgt, cgp, sgt, sgp = np.cos(gwtheta), np.cos(gwphi), np.sin(gwtheta), np.sin(gwphi)
+        mp = sgp * phat[0] + (-cgp) * phat[1]
+        npd = (-cgt * cgp) * phat[0] + (-cgt * sgp) * phat[1] + sgt * phat[2]
+        op = (-sgt * cgp) * phat[0] + (-sgt * sgp) * phat[1] + (-cgt) * phat[2]
+        fac1 = 256 / 5 * mcs ** (5 / 3) * w0 ** (8 / 3)
+        fac2 = 1 / 32 / mcs ** (5 / 3)
+        fac3 = mcs ** (5 / 3) / ds
+        cosMu = -op
+        pd = (pphase / (2 * np.pi * fgw * (1 - cosMu)) / KPC2S if pphase is not None else pdist * np.ones(ncw)) * KPC2S
+        omega_p = w0 * (1 + fac1 * pd * (1 - cosMu)) ** (-3 / 8)
+        cols = (w0, phase0 / 2, w053, fac1, fac2, fac3, 0.5 * (3 + np.cos(2 * inc)), 2 * np.cos(inc), np.cos(2 * psi), np.sin(2 * psi),
+                0.5 * (mp ** 2 - npd ** 2) / (1 + op), (mp * npd) / (1 + op), pd * (1 - cosMu), omega_p,
+                phase0 / 2 + fac2 * (w053 - omega_p ** (-5 / 3)), np.zeros(ncw))
+        for k, c in enumerate(cols):
+            par[:, k] = c
+    return par
+
+
 def add_catalog_of_cws(psr, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_list, phase0_list, psi_list, inc_list, pdist=1.0,
                        pphase=None, psrTerm=True, evolve=True, phase_approx=False, tref=0, chunk_size=10_000_000,
                        signal_name="cw_catalog"):
@@ -107,15 +169,14 @@ def add_catalog_of_cws(psr, gwtheta_list, gwphi_list, mc_list, dist_list, fgw_li
         raise ValueError("all source parameter lists must have the same length")
     mjd = np.asarray(psr.toas.get_mjds().value, dtype=np.float64)
     n = len(mjd)
-    src_d, mjd_d = dv.f64(np.stack(lists, axis=1)), dv.f64(mjd)
-    npar, npart, nchunk = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
-    _lib.call("pta_cw_catalog_workspace", n, ncw, ctypes.byref(npar), ctypes.byref(npart), ctypes.byref(nchunk))
-    par_ws, part_ws, out = dv.empty((npar.value,)), dv.empty((npart.value,)), dv.empty((n,))
-    consts = np.array([SOLAR2S, KPC2S, MPC2S], dtype=np.float64)
+    par = cw_source_params(lists, phat, pdist, pphase)
+    par_d, mjd_d = dv.f64(par), dv.f64(mjd)
+    npart, nchunk = ctypes.c_int64(0), ctypes.c_int(0)
+    _lib.call("pta_cw_catalog_workspace", n, ncw, ctypes.byref(npart), ctypes.byref(nchunk))
+    part_ws, out = dv.empty((npart.value,)), dv.empty((n,))
     mode = 0 if evolve else (1 if phase_approx else 2)
-    _lib.call("pta_cw_catalog", dv.ptr(mjd_d), n, dv.ptr(src_d), ncw, dv.hptr(phat), dv.hptr(consts), ctypes.c_double(pdist),
-              0 if pphase is None else 1, ctypes.c_double(0.0 if pphase is None else pphase), 1 if psrTerm else 0, mode,
-              ctypes.c_double(tref), dv.ptr(par_ws), dv.ptr(part_ws), dv.ptr(out), 0, dv.stream_ptr())
+    _lib.call("pta_cw_catalog", dv.ptr(mjd_d), n, dv.ptr(par_d), ncw, 1 if psrTerm else 0, mode, ctypes.c_double(tref), dv.ptr(part_ws),
+              dv.ptr(out), 0, dv.stream_ptr())
     dt = out.cpu().numpy() * u.s
     psr.update_added_signals("{}_".format(psr.name) + signal_name,
                              {"gwtheta_list": gwtheta_list, "gwphi_list": gwphi_list, "mc_list": mc_list, "dist_list": dist_list,

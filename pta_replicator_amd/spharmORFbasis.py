@@ -18,9 +18,36 @@ def correlated_basis_device(psr_locs, lmax):
     if lmax < 0 or lmax > LMAX_SUPPORTED:
         raise ValueError(f"lmax must be in 0..{LMAX_SUPPORTED}")
     locs_d = dv.f64(psr_locs)
+    zc_d = dv.f64(pair_zeta_cos(psr_locs))
     basis = dv.zeros(((lmax + 1) ** 2, P, P))
-    _lib.call("pta_orf_basis", dv.ptr(locs_d), P, int(lmax), dv.ptr(basis), dv.stream_ptr())
+    _lib.call("pta_orf_basis", dv.ptr(locs_d), dv.ptr(zc_d), P, int(lmax), dv.ptr(basis), dv.stream_ptr())
     return basis
+
+
+def calczeta(phi1, phi2, theta1, theta2):
+    """angular separation of two sky positions with the reference's exact-equality and clamping rules
+    (spharmORFbasis.py:14-35): identical positions -> 0; arguments outside [-1, 1] clamp to pi / 0."""
+    if phi1 == phi2 and theta1 == theta2:
+        return 0.0
+    argument = np.sin(theta1) * np.sin(theta2) * np.cos(phi1 - phi2) + np.cos(theta1) * np.cos(theta2)
+    if argument < -1:
+        return np.pi
+    if argument > 1:
+        return 0.0
+    return float(np.arccos(argument))
+
+
+def pair_zeta_cos(psr_locs):
+    """[P, P, 2]: (zeta_ab, cos zeta_ab) for a <= b, evaluated pair by pair on NumPy float64 scalars like the reference's loop
+    (spharmORFbasis.py:400-408,166) - C libm underneath - so the ill-conditioned l >= 3 sums on the device start from the very
+    numbers the reference uses.  O(P^2) scalar work on the host (0.1 s at 200 pulsars), realisation independent."""
+    P = len(psr_locs)
+    zc = np.zeros((P, P, 2))
+    for a in range(P):
+        for b in range(a, P):
+            z = calczeta(psr_locs[a][0], psr_locs[b][0], psr_locs[a][1], psr_locs[b][1])
+            zc[a, b] = zc[b, a] = (z, np.cos(z))
+    return zc
 
 
 def correlated_basis(psr_locs, lmax):

@@ -46,7 +46,7 @@ void hc_orf_basis(const double *locs, int P, int lmax, double *basis) {
     for (int a = 0; a < P; ++a)
       for (int b = a; b < P; ++b) {
         double v[2 * PTA_ORF_LMAX + 1];
-        pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], v);
+        pta_orf_pair_l(l, locs[2 * a], locs[2 * b], locs[2 * a + 1], locs[2 * b + 1], nullptr, v);
         for (int mi = 0; mi <= 2 * l; ++mi) {
           int k = l * l + mi;
           basis[((int64_t)k * P + a) * P + b] = v[mi];

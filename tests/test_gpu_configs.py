@@ -91,7 +91,7 @@ def test_config4_headline_array_with_cgw():
     for p in (0, 33, 67):   # oracle waveform on three pulsars
         ra, dec = psrs[p].loc["RAJ"] * np.pi / 12, psrs[p].loc["DECJ"] * np.pi / 180
         ref = po.cgw_dt(a.mjd[p], np.pi / 2 - dec, ra, **cw)
-        assert relrms(det[a.off[p]:a.off[p + 1]], ref) < 5e-10
+        assert relrms(det[a.off[p]:a.off[p + 1]], ref) < 2e-10      # evolving phase: see TOL_CGW in tests/test_gpu_parity.py
     _fused_equals_replay(a, 2)
     # one GPU's share of the config (2048 of the 16384 realisations, rank 3's range): batch == one-by-one, finite, and the
     # ensemble variance of one pulsar's residuals is stationary across the shard
@@ -140,7 +140,7 @@ def test_config5_ska_scale_anisotropic():
             gamma_ml = [(-1) ** mm * plus[mm] for mm in range(1, ll + 1)][::-1] + plus
             for mi in range(2 * ll + 1):
                 ref = po.real_rotated_Gammas(mi - ll, ll, locs[a, 0], locs[b, 0], locs[a, 1], locs[b, 1], gamma_ml)
-                assert abs(basis[ll * ll + mi, a, b] - ref) < 1e-9 * (abs(ref) + 0.03)
+                assert abs(basis[ll * ll + mi, a, b] - ref) < 1e-11 * (abs(ref) + 0.03)
     # anisotropy coefficients: isotropic term + 10 % perturbations, redrawn until the ORF is positive definite
     crng = np.random.default_rng(200)
     for _ in range(50):
