@@ -1,8 +1,9 @@
 """Run the UNMODIFIED reference (``/root/reference/pta_replicator``) under stubs.
 
-TEST INFRASTRUCTURE ONLY — this file is imported by ``oracle/gen_golden.py`` (and by
-nothing else).  It only works in the build container, where ``/root/reference`` is
-mounted; the GPU box never runs it.
+TEST / MEASUREMENT INFRASTRUCTURE ONLY — this file is imported by ``oracle/gen_golden.py`` (fixtures) and by
+``oracle/cpu_baseline.py`` (the ``cpu_baseline`` leg of bench.py, kind "reference"), never by the product.  It
+only works where ``/root/reference`` is mounted (the build container); on the GPU box the baseline falls back
+to the NumPy port.
 
 What it provides
 ----------------
