@@ -314,8 +314,20 @@ def main():
     timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), 0, s))
     timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
 
-    gathered = None
-    if world > 1 and not args.no_gather:   # the north_star's gather of the residual arrays to rank 0, pipelined with generation
+    def gather_phase(line):
+        """N > 1: the north_star's gather of the residual arrays to rank 0, pipelined with generation.  Runs LAST and under a
+        watchdog: the multi-GPU path cannot be exercised on the 1-GPU development box, so if it were to hang, rank 0 still
+        prints the line it has (without the gather figure) and every rank exits."""
+        import threading
+
+        def bail():
+            if rank == 0:
+                line["gathered_to_rank0"] = {"error": "timed out after 180 s (watchdog)"}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+        dog = threading.Timer(180.0, bail)
+        dog.daemon = True
+        dog.start()
         try:
             from pta_replicator_amd.distributed import generate_gathered
             full = generate_gathered(eng, world * R, r0=0, chunk=256)      # warm-up (allocations, RCCL channels)
@@ -325,14 +337,19 @@ def main():
             full = generate_gathered(eng, world * R, r0=0, chunk=256)
             barrier()
             tg = time.perf_counter() - tg
-            gathered = {"realisations": world * R, "ms": tg * 1e3, "realisations_per_s": world * R / tg,
-                        "note": "every rank generates its shard in chunks of 256 while the previous chunk travels; rank 0 receives straight into the final tensor"}
             del full
+            res = {"realisations": world * R, "ms": tg * 1e3, "realisations_per_s": world * R / tg,
+                   "note": "every rank generates its shard in chunks of 256 while the previous chunk travels; rank 0 receives straight into the final tensor"}
         except Exception as e:  # pragma: no cover
-            gathered = {"error": str(e)[:300]}
+            res = {"error": str(e)[:300]}
+        dog.cancel()
+        if line is not None:
+            line["gathered_to_rank0"] = res
 
     if rank != 0:
         if world > 1:
+            if not args.no_gather:
+                gather_phase(None)
             dist.destroy_process_group()
         return
 
@@ -412,8 +429,8 @@ def main():
     }
     if td is not None:
         line["td_mode"] = td
-    if gathered is not None:
-        line["gathered_to_rank0"] = gathered
+    if world > 1 and not args.no_gather:
+        gather_phase(line)
     if world == 1 and not args.no_cpu_baseline:
         try:
             line["cpu_baseline"] = cpu_baseline(psrs, noise)

@@ -275,10 +275,15 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
     PTA_LAUNCH_CHECK();
     return PTA_OK;
   }
-  const int w1 = ((w / 2 + CH_NB - 1) / CH_NB) * CH_NB;  // left half: a multiple of 64, < w
+  // right part: a multiple of 64 (about half); the LEFT part takes the remainder, so that an odd width (the first panel's
+  // n mod 128 extra columns) ends up in the very first base block and every later column boundary - hence every later
+  // update's row count - stays aligned to the 64 / 128-wide tiles
+  int cols = (w / 2 / CH_NB) * CH_NB;
+  if (cols < CH_NB) cols = CH_NB;
+  const int w1 = w - cols;
   int rc = pta_factor_panel(A, n, lda, sA, B, c0, w1, info, flags, algo, sp);
   if (rc != PTA_OK) return rc;
-  const int rows = n - (c0 + w1), cols = w - w1;
+  const int rows = n - (c0 + w1);
   const double *L21 = A + (int64_t)(c0 + w1) * lda + c0;
   double *A22 = A + (int64_t)(c0 + w1) * lda + (c0 + w1);
   rc = pta_dgemm_launch(1, rows, cols, w1, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, sA, sA, sA, algo, sp);
@@ -289,8 +294,12 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
 // One dependency chain: right-looking over panels of NBO columns, every launch on `s`.
 static int pta_potrf_chain(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO,
                            hipStream_t s) {
-  for (int k0 = 0; k0 < n; k0 += NBO) {
-    const int nbo = (n - k0 < NBO) ? (n - k0) : NBO;
+  // the FIRST panel also takes n mod 128 columns, so that every trailing update covers a multiple of 128 rows: whole 128 x 128
+  // tiles only (at n = 5000: 1032 + 1024 + ... instead of 31.06, 23.06, ... tiles per side)
+  const int first = (n > NBO) ? NBO + (n % 128) : NBO;
+  for (int k0 = 0; k0 < n;) {
+    const int want = (k0 == 0) ? first : NBO;
+    const int nbo = (n - k0 < want) ? (n - k0) : want;
     const int pend = k0 + nbo;  // one past the panel's last column
     int rc = pta_factor_panel(A, n, lda, strideA, B, k0, nbo, info, flags, algo, s);
     if (rc != PTA_OK) return rc;
@@ -300,6 +309,7 @@ static int pta_potrf_chain(double *A, int n, int64_t lda, int64_t strideA, int B
     double *A22 = A + (int64_t)pend * lda + pend;
     rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
     if (rc != PTA_OK) return rc;
+    k0 = pend;
   }
   return PTA_OK;
 }

@@ -34,9 +34,8 @@ def assemble():
                   ctypes.c_void_p(eng._td_sigma2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_epoch_of.data_ptr() + 4 * o),
                   ctypes.c_void_p(ec2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_Ltd.data_ptr() + 8 * int(eng.td_pos[a])), ld, s)
 info = dv.zeros((P,), dtype=torch.int32)
-for name, flags in (("potrf_default_ms", 0), ("potrf_1chain_ms", _lib.POTRF_NO_LOOKAHEAD), ("potrf_3chains_ms", _lib.POTRF_CHAINS(3)),
-                    ("potrf_4chains_ms", _lib.POTRF_CHAINS(4)), ("potrf_nb2048_2chains_ms", _lib.POTRF_NB(8)), ("potrf_nb512_2chains_ms", _lib.POTRF_NB(2)),
-                    ("potrf_nb256_1chain_ms", _lib.POTRF_NB(1) | _lib.POTRF_NO_LOOKAHEAD)):
+for name, flags in (("potrf_default_ms", 0), ("potrf_1chain_ms", _lib.POTRF_NO_LOOKAHEAD), ("potrf_nb768_ms", _lib.POTRF_NB(3)),
+                    ("potrf_nb1280_ms", _lib.POTRF_NB(5)), ("potrf_nb1536_ms", _lib.POTRF_NB(6)), ("potrf_3chains_ms", _lib.POTRF_CHAINS(3))):
     ts = []
     for rep in range(3):
         assemble(); 
