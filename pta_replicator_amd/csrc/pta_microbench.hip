@@ -19,6 +19,32 @@ __global__ __launch_bounds__(256) void k_mb_mfma(double *out, int iters) {
   if (s == 123.456) out[0] = s;
 }
 
+// the register-tile pattern of the GEMM kernels: 4 A fragments x 4 B fragments -> 16 accumulators, acc[i][j] += a[i] b[j]
+// (16 independent MFMAs between two uses of an accumulator, operands change from one instruction to the next)
+__global__ __launch_bounds__(256, 2) void k_mb_mfma_tile(double *out, int iters) {
+  pta_f64x4 acc[4][4];
+  double a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;
+    b[i] = 1.0 - (threadIdx.x + 32 * i) * 1e-9;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (s == 123.456) out[0] = s;
+}
+
 __global__ __launch_bounds__(256) void k_mb_fma(double *out, int iters) {
   double x[16];
 #pragma unroll
@@ -66,7 +92,7 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
   PTA_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount;
   // kinds 0/1/4: `bytes` in 1..32 selects the number of 256-thread blocks per CU (= waves per SIMD); default 8
-  const int bpc = ((kind == 0 || kind == 1 || kind == 4) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
+  const int bpc = ((kind == 0 || kind == 1 || kind == 4 || kind == 5) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
   hipEvent_t e0, e1;
   PTA_HIP(hipEventCreate(&e0));
   PTA_HIP(hipEventCreate(&e1));
@@ -85,6 +111,10 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
         case 0:
           hipLaunchKernelGGL(k_mb_mfma, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
           work = (double)cus * bpc * 4 * iters * 8.0 * 2048.0 * reps;  // waves * mfma * flop
+          break;
+        case 5:
+          hipLaunchKernelGGL(k_mb_mfma_tile, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 4 * iters * 16.0 * 2048.0 * reps;
           break;
         case 1:
           hipLaunchKernelGGL(k_mb_fma, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);

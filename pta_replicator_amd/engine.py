@@ -293,15 +293,17 @@ class ReplicaEngine(TimeDomainMixin):
         extra = getattr(self, "_delays", None)
         if self._det or extra is not None:
             self.d_det = dv.zeros((N,)) if extra is None else dv.f64(extra)
+            mjd_all = dv.f64(np.concatenate(self.mjd)) if self._det else None     # one upload; the kernel takes host scalars per call
             for kw in self._det or []:
                 for a in range(P):
                     ra, dec = ra_dec(self.psrs[a])
                     par, _, _, _ = det.cgw_parameters(np.pi / 2 - dec, ra, **{k: v for k, v in kw.items() if k != "signal_name"})
-                    mjd_d = dv.f64(self.mjd[a])
-                    par = np.ascontiguousarray(par)
-                    _lib.call("pta_cgw", dv.ptr(mjd_d), len(self.mjd[a]), dv.hptr(par),
-                              ctypes.c_void_p(self.d_det.data_ptr() + 8 * int(self.off[a])), 1, s)
-                    torch.cuda.current_stream().synchronize()
+                    par = np.ascontiguousarray(par)          # copied into the kernel argument at launch: no lifetime issue
+                    o = int(self.off[a])
+                    _lib.call("pta_cgw", ctypes.c_void_p(mjd_all.data_ptr() + 8 * o), len(self.mjd[a]), dv.hptr(par),
+                              ctypes.c_void_p(self.d_det.data_ptr() + 8 * o), 1, s)
+            if self._det:
+                torch.cuda.current_stream().synchronize()      # once, not once per pulsar per source
             pl.det = self.d_det.data_ptr()
         self._prepared = True
         return self
@@ -566,15 +568,18 @@ class ReplicaEngine(TimeDomainMixin):
             sig["wn"] = out
         if pl.ecorr_toa:
             out = dv.zeros((R, N))
+            keep = []                                           # operands stay alive until the single synchronise below
             for a in range(P):
                 ne, n = len(self.ecorrvec[a]), int(self.counts[a])
                 z = np.zeros((R, ne))
                 for r, d in enumerate(draws_list):
                     z[r] = d["ecorr"][a]
                 z_d, ep_d, ec_d = dv.f64(z), dv.i32(self.epoch_of[a]), dv.f64(self.ecorrvec[a])
+                keep += [z_d, ep_d, ec_d]
                 _lib.call("pta_ecorr", dv.ptr(ep_d), dv.ptr(ec_d), n, ne, dv.ptr(z_d), ne, R,
                           ctypes.c_void_p(out.data_ptr() + 8 * int(self.off[a])), N, 0, s)
-                torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream().synchronize()
+            del keep
             sig["ecorr"] = out
         total = dv.zeros((R, N))
         for k in ("rn", "gwb", "wn", "ecorr"):
