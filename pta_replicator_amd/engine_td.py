@@ -57,6 +57,7 @@ class TimeDomainMixin:
         ld = [(n + 1) // 2 * 2 for n in counts]           # even leading dimensions: the product kernel loads double2
         pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(counts, ld)])]).astype(np.int64)
         self.td_ld, self.td_pos = ld, pos
+        self.d_Ltd = None                                  # release a previous factor buffer first: two do not fit at SKA scale
         self.d_Ltd = dv.empty((int(pos[-1]),))
         sigma2 = self.d_wn_a ** 2 + self.d_wn_b ** 2      # (efac sigma)^2 + (efac equad | equad)^2
         self._td_sigma2 = sigma2
