@@ -189,11 +189,8 @@ def td_mode_numbers(eng, R):
     ec2 = (eng.d_ecorr_toa ** 2).contiguous()
 
     def assemble():
-        for a, n in enumerate(counts):
-            o = int(eng.off[a])
-            _lib.call("pta_td_cov_assemble", ctypes.c_void_p(eng.d_Ft.data_ptr() + 8 * o), eng.n_toa, n, eng.K, ctypes.c_void_p(phi.data_ptr() + 8 * a * eng.K),
-                      ctypes.c_void_p(eng._td_sigma2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_epoch_of.data_ptr() + 4 * o),
-                      ctypes.c_void_p(ec2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_Ltd.data_ptr() + 8 * int(eng.td_pos[a])), eng.td_ld[a], s)
+        _lib.call("pta_td_cov_assemble_all", dv.ptr(eng.d_Ft), eng.n_toa, eng.K, dv.ptr(phi), dv.ptr(eng._td_sigma2), dv.ptr(eng.d_epoch_of), dv.ptr(ec2),
+                  dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), s)
 
     uniform = len(set(counts)) == 1
     res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_first * 1e3}

@@ -313,6 +313,15 @@ int pta_engine_generate(const pta_engine_plan *plan_host, const pta_engine_table
 int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, const double *phi, const double *sigma2,
                         const int32_t *epoch_of, const double *ecorr2, double *C, int64_t ldc, void *stream);
 
+/* The same assembly for all pulsars (blocks) of an array in ONE launch of 128 x 128 tiles: block b covers TOAs
+ * [blk_off[b], blk_off[b] + blk_n[b]) of the concatenated axis (Ft columns, sigma2, epoch_of, ecorr2 are indexed by it),
+ * phi[b*K + c] are its prior variances, and its covariance goes to Cbase + blk_pos[b] with row pitch blk_ld[b] (the layout
+ * pta_td_plan describes; all index arrays are device pointers).  max_n = the largest blk_n.                              */
+int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
+                            const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
+                            const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
+                            void *stream);
+
 /* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or
  * pta_rng_fill_normal(stream (TD, pulsar)) in throughput mode.                              */

@@ -88,6 +88,160 @@ extern "C" int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, 
   return PTA_OK;
 }
 
+// The same assembly for ALL pulsars of an array in one launch, 128 x 128 tiles (4 waves as 2 x 2, each 64 x 64 = 4 x 4 MFMA
+// tiles), K slabs of 16 double-buffered in LDS: 4x fewer workgroups and operand loads per output than the 64 x 64 kernel above,
+// no tail between 68 per-pulsar launches.  grid = (lower-triangular tiles of the largest block, blocks).  Both operand slabs
+// are rows of the K-major design matrix (coalesced, conflict-free LDS stores: 16 lanes write 16 consecutive doubles).
+#define TC_T 128
+#define TC_LD 144  // == 16 (mod 32)
+__global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
+                                                      const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
+                                                      const double *__restrict__ ecorr2, double *__restrict__ Cbase,
+                                                      const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
+                                                      const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off) {
+  const int blk = blockIdx.y;
+  const int N = blk_n[blk];
+  const int tix = blockIdx.x;
+  int bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+  while (bm * (bm + 1) / 2 > tix) --bm;
+  const int bn = tix - bm * (bm + 1) / 2;
+  const int m0 = bm * TC_T, n0 = bn * TC_T;
+  if (m0 >= N) return;  // a block smaller than the largest one
+  const int64_t off = blk_off[blk];
+  const int64_t ldc = blk_ld[blk];
+  double *__restrict__ C = Cbase + blk_pos[blk];
+  const double *__restrict__ F = Ft + off;
+  const double *__restrict__ ph = phi ? phi + (int64_t)blk * K : nullptr;
+  __shared__ double smem[4 * TBK * TC_LD];  // operand slabs As[2][16][144], Bs[2][16][144]; reused as the output staging tile
+  double (*As)[TBK][TC_LD] = reinterpret_cast<double (*)[TBK][TC_LD]>(smem);
+  double (*Bs)[TBK][TC_LD] = reinterpret_cast<double (*)[TBK][TC_LD]>(smem + 2 * TBK * TC_LD);
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  pta_f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  const int kr = t >> 4, cq = t & 15;  // slab row (k) and column phase of this thread; columns cq + 16 j
+  double ra[8], rb[8];
+  auto fetch = [&](int k0) {
+    const int gk = k0 + kr;
+    const bool kin = gk < K;
+    const double p = kin ? ph[gk] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gi = m0 + cq + 16 * j, gj = n0 + cq + 16 * j;
+      ra[j] = (kin && gi < N) ? p * F[(int64_t)gk * ldf + gi] : 0.0;
+      rb[j] = (kin && gj < N) ? F[(int64_t)gk * ldf + gj] : 0.0;
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      As[buf][kr][cq + 16 * j] = ra[j];
+      Bs[buf][kr][cq + 16 * j] = rb[j];
+    }
+  };
+  const int nslab = (K + TBK - 1) / TBK;
+  if (nslab > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+  for (int sidx = 0; sidx < nslab; ++sidx) {
+    const int cur = sidx & 1;
+    if (sidx + 1 < nslab) fetch((sidx + 1) * TBK);
+#pragma unroll
+    for (int kk = 0; kk < TBK; kk += 4) {
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[cur][kk + (l >> 4)][wm * 64 + i * 16 + (l & 15)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kk + (l >> 4)][wn * 64 + j * 16 + (l & 15)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+    }
+    if (sidx + 1 < nslab) stash(cur ^ 1);
+    __syncthreads();
+  }
+  // epilogue.  The white and ECORR terms are added in registers (the epochs of the 16 rows and 4 columns a lane owns are read
+  // once); the tile then goes through LDS so that every store instruction of a wave writes ONE whole 1 KB row segment (64 lanes
+  // x 16 bytes) instead of four 128-byte pieces of four different rows: DRAM pages are opened once per row, not per piece.
+  int erow[4][4], ecol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
+      erow[i][r] = (epoch_of && row < N) ? epoch_of[off + row] : -2;
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
+    ecol[j] = (epoch_of && col < N) ? epoch_of[off + col] : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
+      if (row >= N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
+        if (row == col) acc[i][j][r] = acc[i][j][r] + sigma2[off + row];
+        if (col <= row && erow[i][r] == ecol[j]) acc[i][j][r] = acc[i][j][r] + ecorr2[off + row];
+      }
+    }
+  constexpr int SLD = TC_T + 4;                      // staging pitch (doubles): 64 x 132 x 8 B = 67.6 KB <= the 73.7 KB of slabs
+  double (*S)[SLD] = reinterpret_cast<double (*)[SLD]>(smem);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[i * 16 + pta_mfma_row(l, r)][wn * 64 + j * 16 + pta_mfma_col(l)] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int rr = w; rr < 64; rr += 4) {             // wave w stores rows w, w + 4, ... of this half; lane l columns 2l, 2l + 1
+      const int row = m0 + half * 64 + rr;
+      if (row >= N) break;
+      const int col = n0 + 2 * l;
+      const double2 v = *reinterpret_cast<const double2 *>(&S[rr][2 * l]);
+      double *__restrict__ dst = C + (int64_t)row * ldc + col;
+      if (col + 1 <= row)
+        *reinterpret_cast<double2 *>(dst) = v;          // ldc and n0 are even, the block base 16-byte aligned
+      else if (col == row)
+        dst[0] = v.x;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
+                                       const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
+                                       const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
+                                       void *stream) {
+  PTA_REQUIRE(sigma2 && Cbase && blk_pos && blk_ld && blk_n && blk_off && (K == 0 || (Ft && phi)), PTA_E_ARG,
+              "pta_td_cov_assemble_all: NULL argument");
+  PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble_all: ecorr2 missing");
+  PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && max_n > 0 && K >= 0, PTA_E_ARG, "pta_td_cov_assemble_all: n_blocks=%d max_n=%d K=%d",
+              n_blocks, max_n, K);
+  PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_all: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
+  const int64_t nt = pta_cdiv(max_n, TC_T);
+  PTA_REQUIRE(nt * (nt + 1) / 2 < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_all: max_n=%d too large", max_n);
+  hipLaunchKernelGGL(k_td_cov128, dim3((unsigned)(nt * (nt + 1) / 2), n_blocks), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,
+                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
 // out[r, i] (+)= sum_j z[r, j] L[i, j]  =  (Z . L^T)[r, i]; L's strict upper triangle is zero.
 extern "C" int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld_z, int R, double *out, int64_t ld_out,
                            int accumulate, int algo, void *stream) {

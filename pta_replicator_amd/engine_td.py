@@ -54,7 +54,7 @@ class TimeDomainMixin:
         s = dv.stream_ptr()
         pl = self.plan
         counts = [int(c) for c in self.counts]
-        ld = [(n + 1) // 2 * 2 for n in counts]           # even leading dimensions: the product kernel loads double2
+        ld = [(n + 15) // 16 * 16 for n in counts]        # rows start on 128-byte lines (and even: the product kernel loads double2)
         pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(counts, ld)])]).astype(np.int64)
         self.td_ld, self.td_pos = ld, pos
         self.d_Ltd = None                                  # release a previous factor buffer first: two do not fit at SKA scale
@@ -64,15 +64,11 @@ class TimeDomainMixin:
         K = pl.rn_k
         phi = (self.d_amp ** 2).contiguous() if K else None
         ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
-        for a in range(P):
-            o = int(self.off[a])
-            _lib.call("pta_td_cov_assemble",
-                      ctypes.c_void_p(self.d_Ft.data_ptr() + 8 * o) if K else None, N, counts[a], K,
-                      ctypes.c_void_p(phi.data_ptr() + 8 * a * K) if K else None,
-                      ctypes.c_void_p(sigma2.data_ptr() + 8 * o),
-                      ctypes.c_void_p(self.d_epoch_of.data_ptr() + 4 * o) if ecorr2 is not None else None,
-                      ctypes.c_void_p(ecorr2.data_ptr() + 8 * o) if ecorr2 is not None else None,
-                      ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), ld[a], s)
+        # block layout arrays (also what the product kernel reads), then ONE assembly launch over all pulsars
+        self._td_layout = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1])]
+        _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(sigma2),
+                  dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
+                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
         # batched factorisation: runs of consecutive pulsars with the same TOA count share one launch sequence
         info = dv.zeros((P,), dtype=torch.int32)
         flags = 0 if lookahead else _lib.POTRF_NO_LOOKAHEAD
@@ -89,7 +85,7 @@ class TimeDomainMixin:
             a = int(np.nonzero(bad)[0][0])
             raise np.linalg.LinAlgError(f"TD covariance of {self.names[a]} is not positive definite (leading minor {int(bad[a])})")
         blk, n0 = _strips(counts)
-        self._td_keep = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1]), dv.i32(blk), dv.i32(n0)]
+        self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0)]
         tp = _lib.TdPlan()
         tp.Lbase = self.d_Ltd.data_ptr()
         tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in self._td_keep]

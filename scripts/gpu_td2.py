@@ -26,13 +26,10 @@ res["prepare_td_nolook_s"] = wall(lambda: eng.prepare_td(lookahead=False))
 s = dv.stream_ptr()
 n, ld = N, eng.td_ld[0]
 def assemble():
-    K = eng.plan.rn_k
     phi = (eng.d_amp ** 2).contiguous(); ec2 = (eng.d_ecorr_toa ** 2).contiguous()
-    for a in range(P):
-        o = int(eng.off[a])
-        _lib.call("pta_td_cov_assemble", ctypes.c_void_p(eng.d_Ft.data_ptr() + 8 * o), eng.n_toa, n, K, ctypes.c_void_p(phi.data_ptr() + 8 * a * K),
-                  ctypes.c_void_p(eng._td_sigma2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_epoch_of.data_ptr() + 4 * o),
-                  ctypes.c_void_p(ec2.data_ptr() + 8 * o), ctypes.c_void_p(eng.d_Ltd.data_ptr() + 8 * int(eng.td_pos[a])), ld, s)
+    _lib.call("pta_td_cov_assemble_all", dv.ptr(eng.d_Ft), eng.n_toa, eng.plan.rn_k, dv.ptr(phi), dv.ptr(eng._td_sigma2), dv.ptr(eng.d_epoch_of), dv.ptr(ec2),
+              dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], P, N, s)
+    return phi, ec2
 info = dv.zeros((P,), dtype=torch.int32)
 for name, flags in (("potrf_default_ms", 0), ("potrf_1chain_ms", _lib.POTRF_NO_LOOKAHEAD), ("potrf_nb768_ms", _lib.POTRF_NB(3)),
                     ("potrf_nb1280_ms", _lib.POTRF_NB(5)), ("potrf_nb1536_ms", _lib.POTRF_NB(6)), ("potrf_3chains_ms", _lib.POTRF_CHAINS(3))):
