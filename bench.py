@@ -241,10 +241,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry-run aids for a 1-GPU development box (never set by the driver): PTA_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0,
+    # PTA_BENCH_BACKEND=gloo runs the control plane (barrier / all_reduce) without RCCL - together they exercise the N > 1
+    # control flow of this file (env handling, per-rank realisation ranges, max-over-ranks timing, one JSON line) on one GPU
+    if os.environ.get("PTA_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PTA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     import ctypes
