@@ -308,3 +308,19 @@ def test_td_headline_size_vs_numpy():
               ctypes.c_void_p(ec2.data_ptr() + 8 * o), dv.ptr(Cd), n, dv.stream_ptr())
     il = np.tril_indices(n)
     assert np.max(np.abs(Cd.cpu().numpy()[il] - covs[a][il])) < 1e-10 * np.max(np.abs(covs[a]))
+
+
+def test_td_engine_fast_rng_math_is_self_consistent():
+    """engine.rng_fast = 1 reaches the TD kernels through their plan structs: generate_td still equals replay_td on its own
+    dumped deviates, differs from the fp64-transform realisation at the 1e-6 level of the deviates only, and switching it off
+    restores the default bit for bit."""
+    eng, psrs, noise = _small_array(True)
+    eng.prepare_td()
+    ref = eng.generate_td(3, r0=5).cpu().numpy()
+    eng.rng_fast = 1
+    out = eng.generate_td(3, r0=5).cpu().numpy()
+    rep = eng.replay_td([eng.dump_draws_td(5 + r) for r in range(3)]).cpu().numpy()
+    assert np.max(np.abs(out - rep)) < 1e-12 * np.sqrt(np.mean(rep ** 2))
+    assert 0 < np.max(np.abs(out - ref)) < 1e-3 * np.sqrt(np.mean(ref ** 2))
+    eng.rng_fast = 0
+    assert np.array_equal(eng.generate_td(3, r0=5).cpu().numpy(), ref)
