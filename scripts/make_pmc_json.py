@@ -51,7 +51,7 @@ if nf and nw:
             e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
     res[k] = e
 # ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches
-for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov", "k_trsm_mfma", "k_mb_mfma"):
+for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov128", "k_trsm_mfma", "k_mb_mfma(", "k_mb_mfma_tile("):
     m, nm = sums("pmc_mfma", k)
     ms, nt = avg_ms(k)
     if nm and m.get("GRBM_GUI_ACTIVE"):
