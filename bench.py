@@ -411,7 +411,9 @@ def main():
             # fp64_mfma_tile: 4 A x 4 B fragments -> 16 accumulators (the GEMM kernels' pattern): reaches the 78.6 TFLOP/s spec;
             # fp64_mfma_8acc: round 1's loop (8 accumulators, one operand pair): 49 - limited by the dependent-accumulate
             # latency, NOT a ceiling of the matrix pipe
-            for kind, name in ((5, "fp64_mfma_tile_tflops"), (0, "fp64_mfma_8acc_tflops"), (1, "fp64_fma_tflops"), (2, "hbm_write_TBps"), (4, "normals_T_per_s")):
+            # fp64_mfma_plus_fma: both loops on alternating waves of the same SIMDs, SUM of the two rates - they share the DP ALUs
+            for kind, name in ((5, "fp64_mfma_tile_tflops"), (0, "fp64_mfma_8acc_tflops"), (1, "fp64_fma_tflops"), (6, "fp64_mfma_plus_fma_tflops"),
+                               (2, "hbm_write_TBps"), (4, "normals_T_per_s")):
                 _lib.call("pta_microbench", kind, 1 << 30, 2000 if kind in (0, 1) else (20 if kind == 2 else 200), 0, ctypes.byref(res))
                 micro[name] = round(res.value, 3)
         except Exception as e:  # pragma: no cover

@@ -45,6 +45,45 @@ __global__ __launch_bounds__(256, 2) void k_mb_mfma_tile(double *out, int iters)
   if (s == 123.456) out[0] = s;
 }
 
+// do fp64 MFMA and fp64 VALU FMA share the double-precision ALUs?  Even waves run the MFMA register-tile loop, odd waves the FMA
+// loop, on the same SIMDs; the host reports the SUM of both rates (two separate resources would give up to 78 + 68 TFLOP/s)
+__global__ __launch_bounds__(256, 2) void k_mb_mix(double *out, int iters) {
+  double s = 0.0;
+  if (((threadIdx.x >> 6) + blockIdx.x) & 1) {
+    double x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = 1.0 + i * 1e-3 + threadIdx.x * 1e-9;
+    const double a = 1.0000001, b = 1e-9;
+    for (int it = 0; it < 4 * iters; ++it) {   // 64 FMAs x 64 lanes x 2 flop = 8192 flop per 4 inner iterations = half an MFMA batch
+#pragma unroll
+      for (int i = 0; i < 16; ++i) x[i] = fma(x[i], a, b);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x[i];
+  } else {
+    pta_f64x4 acc[4][4];
+    double a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = 1.0 + (threadIdx.x + 64 * i) * 1e-9;
+      b[i] = 1.0 - (threadIdx.x + 32 * i) * 1e-9;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  }
+  if (s == 123.456) out[0] = s;
+}
+
 __global__ __launch_bounds__(256) void k_mb_fma(double *out, int iters) {
   double x[16];
 #pragma unroll
@@ -92,7 +131,7 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
   PTA_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount;
   // kinds 0/1/4: `bytes` in 1..32 selects the number of 256-thread blocks per CU (= waves per SIMD); default 8
-  const int bpc = ((kind == 0 || kind == 1 || kind == 4 || kind == 5) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
+  const int bpc = ((kind == 0 || kind == 1 || kind == 4 || kind == 5 || kind == 6) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
   hipEvent_t e0, e1;
   PTA_HIP(hipEventCreate(&e0));
   PTA_HIP(hipEventCreate(&e1));
@@ -115,6 +154,10 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
         case 5:
           hipLaunchKernelGGL(k_mb_mfma_tile, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
           work = (double)cus * bpc * 4 * iters * 16.0 * 2048.0 * reps;
+          break;
+        case 6:  // half the waves: 16 MFMAs x 2048 flop per iteration; the other half: 4 x 16 FMAs x 64 lanes x 2 flop per iteration
+          hipLaunchKernelGGL(k_mb_mix, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 2 * iters * (16.0 * 2048.0 + 4 * 16.0 * 64.0 * 2.0) * reps;
           break;
         case 1:
           hipLaunchKernelGGL(k_mb_fma, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
