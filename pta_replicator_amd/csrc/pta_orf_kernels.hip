@@ -291,27 +291,24 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
   return pta_factor_panel(A, n, lda, sA, B, c0 + w1, cols, info, flags, algo, sp);
 }
 
-// One dependency chain: right-looking over panels of NBO columns, every launch on `s`.
-static int pta_potrf_chain(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO,
-                           hipStream_t s) {
+// One step of a dependency chain (right-looking over panels of NBO columns, every launch on `s`): factor the panel that
+// starts at column k0, then apply it to everything to its right in ONE product.  Returns the next panel's first column in *k0_io.
+static int pta_potrf_step(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, int *k0_io,
+                          hipStream_t s) {
   // the FIRST panel also takes n mod 128 columns, so that every trailing update covers a multiple of 128 rows: whole 128 x 128
   // tiles only (at n = 5000: 1032 + 1024 + ... instead of 31.06, 23.06, ... tiles per side)
-  const int first = (n > NBO) ? NBO + (n % 128) : NBO;
-  for (int k0 = 0; k0 < n;) {
-    const int want = (k0 == 0) ? first : NBO;
-    const int nbo = (n - k0 < want) ? (n - k0) : want;
-    const int pend = k0 + nbo;  // one past the panel's last column
-    int rc = pta_factor_panel(A, n, lda, strideA, B, k0, nbo, info, flags, algo, s);
-    if (rc != PTA_OK) return rc;
-    const int rows = n - pend;
-    if (rows <= 0) break;
-    const double *L21 = A + (int64_t)pend * lda + k0;
-    double *A22 = A + (int64_t)pend * lda + pend;
-    rc = pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
-    if (rc != PTA_OK) return rc;
-    k0 = pend;
-  }
-  return PTA_OK;
+  const int k0 = *k0_io;
+  const int want = (k0 == 0 && n > NBO) ? NBO + (n % 128) : NBO;
+  const int nbo = (n - k0 < want) ? (n - k0) : want;
+  const int pend = k0 + nbo;  // one past the panel's last column
+  int rc = pta_factor_panel(A, n, lda, strideA, B, k0, nbo, info, flags, algo, s);
+  if (rc != PTA_OK) return rc;
+  *k0_io = pend;
+  const int rows = n - pend;
+  if (rows <= 0) return PTA_OK;
+  const double *L21 = A + (int64_t)pend * lda + k0;
+  double *A22 = A + (int64_t)pend * lda + pend;
+  return pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
 }
 
 // Right-looking over panels of NB = 1024 columns; the trailing update of a panel is ONE product with K = NB over the
@@ -338,18 +335,32 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
   if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   if (nchain == 1) {
-    int rc = pta_potrf_chain(A, n, lda, strideA, B, info, flags, algo, NBO, s);
-    if (rc != PTA_OK) return rc;
+    for (int k0 = 0; k0 < n;) {
+      int rc = pta_potrf_step(A, n, lda, strideA, B, info, flags, algo, NBO, &k0, s);
+      if (rc != PTA_OK) return rc;
+    }
   } else {
     pta_potrf_ctx *cx = nullptr;
     int rc = pta_potrf_ctx_get(&cx);
     if (rc != PTA_OK) return rc;
     PTA_HIP(hipEventRecord(cx->ev_in, s));
+    // the launches are ENQUEUED panel step by panel step across the chains (a chain's ~235 launches take the host longer than
+    // the first panel takes the device: enqueued chain after chain, the second chain starts late - 13 ms under rocprofv3 - and finishes alone; starting chain c only after chain c-1's first panel, so
+    // that panel phases meet trailing updates from the start, measured 2 ms SLOWER: the panel kernels are real work, not idle time)
+    int k0[PTA_POTRF_MAX_CHAINS] = {0, 0, 0, 0};
+    for (int step = 0, live = nchain; live > 0; ++step) {
+      live = 0;
+      for (int c = 0; c < nchain; ++c) {
+        if (k0[c] >= n) continue;
+        const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
+        if (step == 0) PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
+        rc = pta_potrf_step(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, &k0[c],
+                            cx->chain[c]);
+        if (rc != PTA_OK) return rc;
+        if (k0[c] < n) ++live;
+      }
+    }
     for (int c = 0; c < nchain; ++c) {
-      const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
-      PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
-      rc = pta_potrf_chain(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, cx->chain[c]);
-      if (rc != PTA_OK) return rc;
       PTA_HIP(hipEventRecord(cx->ev_out[c], cx->chain[c]));
       PTA_HIP(hipStreamWaitEvent(s, cx->ev_out[c], 0));  // join: the caller's stream continues after every chain
     }

@@ -32,7 +32,7 @@ def assemble():
     return phi, ec2
 info = dv.zeros((P,), dtype=torch.int32)
 for name, flags in (("potrf_default_ms", 0), ("potrf_1chain_ms", _lib.POTRF_NO_LOOKAHEAD), ("potrf_nb768_ms", _lib.POTRF_NB(3)),
-                    ("potrf_nb1280_ms", _lib.POTRF_NB(5)), ("potrf_nb1536_ms", _lib.POTRF_NB(6)), ("potrf_3chains_ms", _lib.POTRF_CHAINS(3))):
+                    ("potrf_nb1280_ms", _lib.POTRF_NB(5)), ("potrf_3chains_ms", _lib.POTRF_CHAINS(3)), ("potrf_4chains_ms", _lib.POTRF_CHAINS(4))):
     ts = []
     for rep in range(3):
         assemble(); 

@@ -137,7 +137,9 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
     rng = np.random.default_rng(n)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
-    for flags in (lib.POTRF_VALU, 0, lib.POTRF_SUBSTITUTION, lib.POTRF_NO_LOOKAHEAD):   # VALU cross-check, default (MFMA), ...
+    # VALU cross-check, default (MFMA), substitution solves, one chain, and 256-wide panels on 3 / 4 chains
+    for flags in (lib.POTRF_VALU, 0, lib.POTRF_SUBSTITUTION, lib.POTRF_NO_LOOKAHEAD,
+                  lib.POTRF_CHAINS(3) | lib.POTRF_NB(1), lib.POTRF_CHAINS(4) | lib.POTRF_NB(1)):
         L = rn.cholesky_device(dv.f64(A), flags).cpu().numpy()
         ref = np.linalg.cholesky(A)
         assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, flags)
