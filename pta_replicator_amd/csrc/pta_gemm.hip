@@ -42,6 +42,20 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  // beta != 0: this thread's 16 elements of C are requested BEFORE the K loop, from clamped - always valid - addresses (only
+  // the stores are predicated): the panel-internal updates this kernel serves have K = 64, four slabs, so read one element at
+  // a time after the last MFMA the C tile was most of the kernel's duration
+  const int rowb = m0 + wm * 32 + (l >> 4), colb = n0 + wn * 32 + pta_mfma_col(l);
+  double cv[2][2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cv[i][j][r] = C[(int64_t)min(rowb + i * 16 + 4 * r, M - 1) * ldc + min(colb + j * 16, N - 1)];
+  }
 
   for (int k0 = 0; k0 < K; k0 += GBK) {
     {  // A slab: 64 rows x 16 k, 4 consecutive k per thread
@@ -91,13 +105,10 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int row = m0 + wm * 32 + i * 16 + pta_mfma_row(l, r);
-        int col = n0 + wn * 32 + j * 16 + pta_mfma_col(l);
-        if (row < M && col < N && (!lower_only || col <= row)) {
-          int64_t o = (int64_t)row * ldc + col;
-          double v = alpha * acc[i][j][r];
-          C[o] = (beta == 0.0) ? v : v + beta * C[o];
-        }
+        const int row = rowb + i * 16 + 4 * r, col = colb + j * 16;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v = fma(beta, cv[i][j][r], v);
+        if (row < M && col < N && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
       }
 }
 

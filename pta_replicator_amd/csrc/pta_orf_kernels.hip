@@ -178,8 +178,6 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
   __shared__ double X[CH_NB][CH_LD];
   double *M = A + (int64_t)blockIdx.y * sA;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
-  const int r0 = k0 + nb + blockIdx.x * CH_NB;
-  const int rows = min(CH_NB, nrow - r0);
   for (int i = t >> 6; i < CH_NB; i += 4)
     for (int c = t & 63; c < CH_NB; c += 64) {
       // tile element (i, c) of the factored diagonal block, read along its row (coalesced): above the diagonal it is
@@ -191,37 +189,45 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
         else if (c == i) v = 1.0 / m;
       }
       Li[c][i] = v;
-      X[i][c] = (i < rows && c < nb) ? M[(int64_t)(r0 + i) * n + (k0 + c)] : 0.0;
     }
-  __syncthreads();
   const int wm = w >> 1, wn = w & 1;
-  pta_f64x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-  for (int kk = 0; kk < CH_NB; kk += 4) {
-    double a[2], b[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) a[i] = X[wm * 32 + i * 16 + (l & 15)][kk + (l >> 4)];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = Li[wn * 32 + j * 16 + (l & 15)][kk + (l >> 4)];
+  const int nblk = (nrow - k0 - nb + CH_NB - 1) / CH_NB;
+  // grid-stride over the 64-row blocks below the diagonal block: the inverse is staged once per workgroup, not once per block
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int r0 = k0 + nb + blk * CH_NB;
+    const int rows = min(CH_NB, nrow - r0);
+    for (int i = t >> 6; i < CH_NB; i += 4)
+      for (int c = t & 63; c < CH_NB; c += 64) X[i][c] = (i < rows && c < nb) ? M[(int64_t)(r0 + i) * n + (k0 + c)] : 0.0;
+    __syncthreads();
+    pta_f64x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+      for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < CH_NB; kk += 4) {
+      double a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = X[wm * 32 + i * 16 + (l & 15)][kk + (l >> 4)];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = Li[wn * 32 + j * 16 + (l & 15)][kk + (l >> 4)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int row = wm * 32 + i * 16 + pta_mfma_row(l, r);
+          int col = wn * 32 + j * 16 + pta_mfma_col(l);
+          if (row < rows && col < nb) M[(int64_t)(r0 + row) * n + (k0 + col)] = acc[i][j][r];
+        }
+    __syncthreads();  // every wave is done with X before the next block overwrites it
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int row = wm * 32 + i * 16 + pta_mfma_row(l, r);
-        int col = wn * 32 + j * 16 + pta_mfma_col(l);
-        if (row < rows && col < nb) M[(int64_t)(r0 + row) * n + (k0 + col)] = acc[i][j][r];
-      }
 }
 
 __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t sA) {
@@ -268,8 +274,11 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
     PTA_LAUNCH_CHECK();
     const int rows = n - c0 - w;
     if (rows <= 0) return PTA_OK;
-    if (algo && !(flags & PTA_POTRF_SUBSTITUTION))
-      hipLaunchKernelGGL(k_trsm_mfma, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
+    if (algo && !(flags & PTA_POTRF_SUBSTITUTION)) {
+      // about 1024 workgroups per launch (2 resident per CU x 2 rounds), each walking its share of the row blocks
+      const int nblk = pta_cdiv(rows, CH_NB), per = pta_cdiv(1024, B);
+      hipLaunchKernelGGL(k_trsm_mfma, dim3(nblk < per ? nblk : per, B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
+    }
     else
       hipLaunchKernelGGL(k_trsm, dim3(pta_cdiv(rows, CH_NB), B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
     PTA_LAUNCH_CHECK();
