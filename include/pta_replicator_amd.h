@@ -270,7 +270,8 @@ typedef struct {
   int32_t synth_variant;      /* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs
                                  per workgroup), workgroups dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same
                                  kernel in plain linear workgroup order (A/B); 4 / 6 / 8 = all-VALU kernel compiled for that many
-                                 waves per SIMD (kept for cross-checks) */
+                                 waves per SIMD (kept for cross-checks); 100 + k (k <= 64) = the default kernel with k KB of unused
+                                 dynamic LDS per workgroup (occupancy probe, scripts/gpu_synth_occupancy.py) */
 } pta_engine_plan;
 
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */

@@ -266,17 +266,22 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
               "pta_engine_synth: GWB inputs missing");
   PTA_REQUIRE(!p.wn_a || p.wn_b, PTA_E_ARG, "pta_engine_synth: wn_b missing");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
-  const int variant = p.synth_variant;  // 0 = MFMA kernel (default); 1 = same, linear workgroup order; 4 / 6 / 8 = all-VALU kernel
+  // 0 = MFMA kernel (default); 1 = same, linear workgroup order; 4 / 6 / 8 = all-VALU kernel; 100 + k = MFMA kernel with k KB of
+  // unused dynamic LDS per workgroup - the occupancy probe of scripts/gpu_synth_occupancy.py: the 34 KB ECORR staging buffer allows 4
+  // workgroups per CU (+12 KB: 3, +20 KB: 2).  Measured step time 10.3 / 7.2 / 5.9 / 5.5 ms at 1 / 2 / 3 / 4 workgroups; a two-pass
+  // staging variant (17 KB, 6 per CU, 3 barriers) measured 6.0 ms at 6 AND when padded back to 4: occupancy is saturated at 4.
+  const int variant = p.synth_variant;
   const int rng_fast = p.rng_fast ? 1 : 0;
-  if (variant == 0 || variant == 1) {  // 1: same kernel, plain linear workgroup order (A/B of the XCD mapping)
-    const int xcd = variant == 0 ? 1 : 0;
+  if (variant == 0 || variant == 1 || (variant >= 100 && variant <= 164)) {  // 1: plain linear workgroup order (A/B of the XCD mapping)
+    const int xcd = variant == 1 ? 0 : 1;
+    const unsigned pad = variant >= 100 ? (unsigned)(variant - 100) * 1024u : 0u;
     const int64_t total = (int64_t)pta_cdiv(R, ENG_MR) * p.n_tiles, nwg = ((total + 7) >> 3) << 3;
     PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_engine_synth: %lld workgroups exceed one launch", (long long)nwg);
     if (rng_fast)
-      hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R, out,
+      hipLaunchKernelGGL(k_engine_synth_mfma<true>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), pad, pta_stream(stream), p, seed, r0, R, out,
                          ld_out, xcd);
     else
-      hipLaunchKernelGGL(k_engine_synth_mfma<false>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), 0, pta_stream(stream), p, seed, r0, R, out,
+      hipLaunchKernelGGL(k_engine_synth_mfma<false>, dim3((unsigned)nwg), dim3(PTA_ENGINE_TILE), pad, pta_stream(stream), p, seed, r0, R, out,
                          ld_out, xcd);
     PTA_LAUNCH_CHECK();
     return PTA_OK;
