@@ -380,7 +380,7 @@ int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, in
  * 2: HBM write GB/s over `bytes`, 3: HBM copy GB/s, 4: Philox+Box-Muller G normals/s, 5: fp64 MFMA in the GEMM kernels'
  * register-tile pattern (4 A x 4 B fragments -> 16 accumulators), 6: that MFMA loop
  * and the FMA loop on alternating waves of the same SIMDs (sum of both rates: do they share the fp64 ALUs?).  kinds 0 / 1 / 4 / 5: `bytes` in 1..32 = 256-thread blocks per CU.       */
-int pta_microbench(int kind, int64_t bytes, int iters, int option, double *result_host);   /* option: rng_fast of kind 4 */
+int pta_microbench(int kind, int64_t bytes, int iters, int option, double *result_host);   /* option of kind 4: 0 = default fp64 transform, 1 = rng_fast, 2 = the polynomial fp64 transform (A/B) */
 
 /* self-test of the fp64 MFMA lane layout used by the GEMM kernels: returns 0 when a 16x16x4
  * product with asymmetric operands matches the scalar result on the device.                */

@@ -107,6 +107,10 @@ __global__ __launch_bounds__(PTA_FFT_THREADS, 4) void k_gwb_czt(uint64_t seed, u
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
   const int Kf = Nf - 2;
+  if (RNG) {
+    pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+    __syncthreads();
+  }
   const uint64_t real = r0 + (uint64_t)(row / P);
   const uint32_t strm = pta_stream_id(PTA_STREAM_GWB, (uint32_t)(row % P));
   const pta_cplx *pre2 = reinterpret_cast<const pta_cplx *>(pre);

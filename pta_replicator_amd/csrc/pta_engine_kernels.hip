@@ -11,6 +11,8 @@
 // coef[(r*P + a)*K + c] = amp[a*K + c] * z,  z = deviate c of stream (RN, a)   (red_noise.py:126-127)
 __global__ void k_engine_rn_coef(uint64_t seed, uint64_t r0, int R, int P, int K, const double *__restrict__ amp,
                                  double *__restrict__ coef, int fast) {
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
   int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (r, a, pair)
   int hp = K / 2;
   int total = R * P * hp;
@@ -50,6 +52,8 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
   // realisation groups are the FAST grid axis: the workgroups that share a tile's Ft columns / noise vectors run
   // back to back and hit L2 (with tiles fastest every sweep re-read the whole 163 MB design matrix from HBM:
   // rocprofv3 FETCH_SIZE 11.6 GB per launch against 2.6 GB written)
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
   const int tile = blockIdx.y;
   const int rb = blockIdx.x * ENG_RB;
   const int a = pl.tile_psr[tile];
@@ -154,7 +158,9 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
   const int nrg = (R + ENG_MR - 1) / ENG_MR;
   const int64_t total = (int64_t)nrg * pl.n_tiles, chunk = (total + 7) >> 3;
   const int64_t item = xcd_aware ? (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
-  if (item >= total) return;
+  if (item >= total) return;  // workgroup-uniform
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
   const int tile = (int)(item / nrg);
   const int rb = (int)(item - (int64_t)tile * nrg) * ENG_MR;
   const int a = pl.tile_psr[tile];

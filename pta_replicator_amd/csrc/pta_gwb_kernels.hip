@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256, MINW) void k_gwb_idft_sym_rng(uint64_t seed, u
   double2 regs[C::NLD];
 #pragma unroll
   for (int q = 0; q < C::NLD; ++q) lds2[q * 256] = src[q * 256];
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
   __syncthreads();
   const int kk = l >> 4;
   for (int ks = 0; ks < nstep; ++ks) {

@@ -113,11 +113,22 @@ __global__ void k_mb_copy(const double2 *__restrict__ in, double2 *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_mb_rng(double *out, int iters, int fast) {
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
   double s = 0.0;
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   for (int it = 0; it < iters; ++it) {
     double z0, z1;
-    pta_normal_pair(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p, z0, z1, fast);
+    if (fast == 2) {  // the polynomial (fdlibm-style) transform the table-driven default replaced: A/B of the two
+      double u1, u2, sn, cs;
+      pta_uniform_pair(pta_philox_draw(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p), u1, u2);
+      const double rad = pta_sqrt_pos(pta_neg2log_poly(u1));
+      pta_sincos_2pi_poly(u2, sn, cs);
+      z0 = rad * cs;
+      z1 = rad * sn;
+    } else {
+      pta_normal_pair(42, (uint64_t)it, pta_stream_id(PTA_STREAM_WN, 0), p, z0, z1, fast);
+    }
     s += z0 * z1;
   }
   if (s == 123.456) out[0] = s;
@@ -172,7 +183,7 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
           work = 2.0 * (double)nbytes * reps;
           break;
         case 4:
-          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, option ? 1 : 0);
+          hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, option);
           work = (double)cus * bpc * 256 * iters * 2.0 * reps;  // normals
           break;
         default:

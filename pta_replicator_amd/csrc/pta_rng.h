@@ -14,6 +14,7 @@
 #pragma once
 #include <stdint.h>
 #include <math.h>
+#include "pta_rng_tables.h"
 
 #ifndef PTA_HD
 #if defined(__HIPCC__)
@@ -144,11 +145,12 @@ PTA_HD double pta_sqrt_pos(double x) {  // x >= 0; exact zero is nudged to 1e-30
 #endif
 }
 
+// (kept as the cross-check of the table-driven transform below and for the microbenchmark's A/B; not on the product path)
 // -2 ln(u) for u in (0,1].  Classic argument reduction u = 2^e m, m in [sqrt(1/2), sqrt(2)), then
 // ln(1+f) = f - (f^2/2 - s (f^2/2 + R(s^2))), s = f/(2+f), with the degree-14 minimax R of Sun's fdlibm
 // (public domain, e_log.c; < 1 ulp).  About a third of the instructions of the generic library log(),
 // which matters because Gaussian generation is the VALU-bound part of the whole pipeline.
-PTA_HD double pta_neg2log(double u) {
+PTA_HD double pta_neg2log_poly(double u) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
   const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
@@ -174,7 +176,7 @@ PTA_HD double pta_neg2log(double u) {
 
 // sin(2 pi u), cos(2 pi u) for u in [0,1): exact reduction to the nearest quarter turn, then the fdlibm
 // kernels (k_sin.c / k_cos.c, |x| <= pi/4, < 1 ulp) and a quadrant rotation.
-PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
+PTA_HD void pta_sincos_2pi_poly(double u, double &sn, double &cs) {
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
@@ -194,8 +196,77 @@ PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
   cs = (k == 1 || k == 2) ? -c1 : c1;
 }
 
+
+// ---- table-driven transform (default) --------------------------------------------------------------------------------------
+// Gaussian generation is the VALU-bound part of the whole pipeline (~2/3 of the fused kernel's instructions), so the two
+// transcendentals trade polynomial length for one 16-byte table read each.  The table (pta_rng_tables.h, 2.5 KB) is staged into
+// LDS once per workgroup - pta_rng_stage_tables() + a barrier at the top of every kernel that draws - because 64 lanes reading
+// 64 random 16-byte entries cost the CU's single texture-addresser as many cycles from global memory as the instructions saved.
+//
+//  -2 ln(u), u = 2^e m: the top 7 mantissa bits j select (c_j, T_j = 2 ln c_j) with c_j ~ 1 / (centre of the interval), the
+//    mantissa is re-centred to m' in [0.707, 1.414) by integer arithmetic on the exponent field (k = e or e + 1), and
+//        -2 ln u = -k 2 ln2 + T_j - 2 ln(1 + r),   r = m' c_j - 1  (one fma, |r| <= 2^-8),
+//    with -2 ln(1 + r) = -2 r + r^2 (1 - 2/3 r + 1/2 r^2 - 2/5 r^3 + 1/3 r^4 - 2/7 r^5), truncation 2e-18 relative.  Near u = 1
+//    the table entry is (1, 0), so the result keeps its accuracy RELATIVE to itself where the Box-Muller radius goes to zero.
+//    ~25 instructions against 38 for the fdlibm-style evaluation above (no division, no degree-14 polynomial).
+//  sin / cos(2 pi u): nearest 32nd of a turn from the table (exact zeros at the quarter turns), remainder |x| <= pi / 32 through
+//    the Taylor series to x^9 / x^8 (truncation < 3e-17), one rotation: ~23 instructions against 37 (no quadrant selects).
+// Accuracy (scripts/gpu_rng_accuracy.py): every deviate within 4 ulp of an 80-bit evaluation of the same uniforms.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double *pta_rng_lds() {
+  __shared__ double __attribute__((aligned(16))) tab[PTA_RNG_TAB_DOUBLES];
+  return tab;
+}
+// every thread of the workgroup calls this once, before its first draw; the caller then issues __syncthreads()
+__device__ __forceinline__ void pta_rng_stage_tables() {
+  double *t = pta_rng_lds();
+  for (int i = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z); i < PTA_RNG_TAB_DOUBLES; i += blockDim.x * blockDim.y * blockDim.z)
+    t[i] = pta_rng_tab[i];
+}
+#define PTA_RNG_TABLE pta_rng_lds()
+#else
+PTA_HD void pta_rng_stage_tables() {}  // host pass of hipcc / host twin: the table is read in place
+#define PTA_RNG_TABLE pta_rng_tab
+#endif
+
+PTA_HD double pta_neg2log(double u) {
+  const double L2H = 1.38629436073824763298e+00, L2L = 3.81642985854117540004e-10;  // 2 ln2 = L2H + L2L, L2H with 21 trailing zero bits
+  const uint64_t b = pta_double_to_bits(u);
+  const uint32_t hi = (uint32_t)(b >> 32);
+  const uint32_t j = (hi >> (20 - PTA_RNG_LOG_BITS)) & ((1u << PTA_RNG_LOG_BITS) - 1u);
+  // -k: the add carries into the exponent field iff j >= PTA_RNG_LOG_CENTRED
+  const int nk = 1023 - (int)((hi + (((1u << PTA_RNG_LOG_BITS) - PTA_RNG_LOG_CENTRED) << (20 - PTA_RNG_LOG_BITS))) >> 20);
+  const uint32_t hi2 = hi + ((uint32_t)nk << 20);                                      // exponent field of m' = u 2^-k
+  const double m = pta_bits_to_double(((uint64_t)hi2 << 32) | (b & 0xFFFFFFFFull));
+  const double *e = PTA_RNG_TABLE + 2 * j;
+  const double c = e[0], T = e[1];
+  const double r = fma(m, c, -1.0);
+  const double W = pta_fma_k(r, pta_fma_k(r, pta_fma_k(r, pta_fma_k(r, fma(r, -2.85714285714285698425e-01, 3.33333333333333314830e-01),
+                                                   -4.00000000000000022204e-01), 0.5), -6.66666666666666629659e-01), 1.0);
+  const double t = fma(r * r, W, -2.0 * r);
+  const double nkd = (double)nk;
+  return fma(nkd, L2H, T + fma(nkd, L2L, t));
+}
+
+PTA_HD void pta_sincos_2pi(double u, double &sn, double &cs) {
+  const double kd = rint((double)PTA_RNG_SC_N * u);            // 0..32
+  const double r = fma(kd, -1.0 / PTA_RNG_SC_N, u);            // [-1/64, 1/64], exact
+  const int k = (int)kd & (PTA_RNG_SC_N - 1);
+  const double *e = PTA_RNG_TABLE + PTA_RNG_SC_OFF + 2 * k;
+  const double sa = e[0], ca = e[1];
+  const double x = 6.283185307179586 * r;
+  const double z = x * x;
+  const double ps = pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, fma(z, 2.75573192239858925110e-06, -1.98412698412698412526e-04), 8.33333333333333321769e-03),
+                                       -1.66666666666666657415e-01), 1.0);
+  const double cx = pta_fma_k(z, pta_fma_k(z, pta_fma_k(z, fma(z, 2.48015873015873015658e-05, -1.38888888888888894189e-03), 4.16666666666666643537e-02),
+                                       -0.5), 1.0);
+  const double sx = x * ps;
+  sn = fma(sa, cx, ca * sx);
+  cs = fma(ca, cx, -(sa * sx));
+}
+
 // Box-Muller: (z0, z1) iid N(0,1).
-// fast = 0 (default): fp64 transform, every step < 1 ulp; the deviates sit within 3 ulp of an 80-bit evaluation of the same
+// fast = 0 (default): fp64 table-driven transform; the deviates sit within a few ulp of an 80-bit evaluation of the same
 //           uniforms (scripts/gpu_rng_accuracy.py, 2^21 deviates) and are reproducible on the host to ~1e-16.
 // fast = 1 ("fast RNG math", opt-in): the SAME uniforms through the hardware fp32 transcendentals (v_log_f32, v_sqrt_f32,
 //           v_sin_f32 / v_cos_f32, which take their argument in turns) - deviates accurate to ~1e-6, a statistically

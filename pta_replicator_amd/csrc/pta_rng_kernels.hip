@@ -24,6 +24,8 @@ extern "C" int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int 
 
 __global__ void k_fill_normal(uint64_t seed, uint64_t r0, uint32_t stream_id, int npairs, int interleave,
                               double *__restrict__ z0, double *__restrict__ z1, int64_t ld, int fast) {
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
   if (p >= npairs) return;

@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   };
   fetch(0);
   stash(0);
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
   __syncthreads();
   for (int s = 0; s < nslab; ++s) {
     const int cur = s & 1;
