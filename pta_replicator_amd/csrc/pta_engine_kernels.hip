@@ -144,6 +144,8 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 // realisation (l & 15), bin (l >> 4) and the design-matrix entry of bin (l >> 4), TOA (l & 15) of each tile, and receives the
 // sums for realisations (l >> 4) + 4 g, TOA (l & 15): exactly the (4 TOAs x 4 realisations) it then finishes on the VALU
 // (GWB interpolation, EFAC/EQUAD and ECORR deviates, deterministic term) and stores as 128-byte row segments.
+// two doubles loaded as one 16-byte access from an address that is only 8-byte aligned (global loads need dword alignment)
+typedef double pta_f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 #define ENG_MR 16  // realisations per workgroup (MFMA M)
 #define ENG_ZPITCH (2 * PTA_ENGINE_EPMAX + 8)  // = 16 mod 32 doubles: the two realisation rows a half-wave reads sit on disjoint banks
 
@@ -192,19 +194,37 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
     const int ra = min(rb + col, R - 1);
     const double *__restrict__ cf = pl.rn_coef + ((int64_t)ra * P + a) * K;
     const double *__restrict__ Fb = pl.Ft + start;
-#pragma unroll 5
-    for (int k0 = 0; k0 < K; k0 += 4) {  // unrolled so that several K-steps' loads are in flight (4 waves per SIMD hide little)
-      const int k = k0 + quad;
-      const bool kin = k < K;
-      const double av = kin ? cf[k] : 0.0;
-      double bv[4];
+    // branch-free body - every load is unconditional, from a clamped (always valid) address: a bin beyond K enters with a zero
+    // coefficient, a TOA beyond the tile's count lands in an accumulator column the epilogue never stores - so that the compiler
+    // can unroll the loop and keep several K-steps' loads in flight (with predicated loads it emitted one exec-masked block and
+    // one s_waitcnt vmcnt(0) per step: 15 serialised L2 round trips per workgroup)
+    int tcl[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ti = tbase + 16 * j;
-        bv[j] = (kin && ti < count) ? Fb[(int64_t)k * pl.ldf + ti] : 0.0;
-      }
+    for (int j = 0; j < 4; ++j) tcl[j] = min(tbase + 16 * j, count - 1);
+    // three K-steps in flight: the operands of steps k0 + 4 and k0 + 8 are being loaded while step k0 runs on the matrix cores
+    // (rotation by name, not by register moves; loads past K re-read bin K - 1 and are dropped)
+    auto ld = [&](int k0, double &av, double (&bv)[4]) {
+      const int k = k0 + quad, kc = min(k, K - 1);
+      const double a_ld = cf[kc];
+      av = (k < K) ? a_ld : 0.0;
+      const double *__restrict__ Fk = Fb + (int64_t)kc * pl.ldf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Fk[tcl[j]];
+    };
+    auto mm = [&](double av, const double (&bv)[4]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j] = pta_mfma_f64(av, bv[j], acc[j]);
+    };
+    double a0, a1, a2, b0[4], b1[4], b2[4];
+    ld(0, a0, b0);
+    ld(4, a1, b1);
+    for (int k0 = 0; k0 < K; k0 += 12) {
+      ld(k0 + 8, a2, b2);
+      mm(a0, b0);
+      ld(k0 + 12, a0, b0);
+      mm(a1, b1);  // steps past K carry a zero coefficient: no exits inside the rotation
+      ld(k0 + 16, a1, b1);
+      mm(a2, b2);
     }
   }
   const uint32_t strm_wn = pta_stream_id(PTA_STREAM_WN, (uint32_t)a);
@@ -224,8 +244,8 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
       for (int g = 0; g < 4; ++g) {
         const int r = min(rb + quad + 4 * g, R - 1);
         const double *gp = pl.gw_G + ((int64_t)r * P + a) * pl.gw_npts;
-        const double y0 = gp[jl];
-        v[g] = v[g] + ((gp[jl + 1] - y0) * wgt + y0);
+        const pta_f64x2_a8 y = *reinterpret_cast<const pta_f64x2_a8 *>(gp + jl);  // both bracket samples in one 16-byte load
+        v[g] = v[g] + ((y.y - y.x) * wgt + y.x);
       }
     }
     if (pl.wn_a) {  // EFAC/EQUAD (white_noise.py:105-109)
