@@ -186,6 +186,16 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
   }
   const int col = l & 15, quad = l >> 4;
   const int tbase = wv * 64 + col;  // TOA (inside the tile) of MFMA tile 0; tile j adds 16 j
+  // No predicated stores anywhere below: a lane beyond the tile's count works on the tile's LAST TOA and a realisation row beyond
+  // R on realisation R - 1 - same counters, same operands, bit-identical value - and stores it again to the same address.  (Stores
+  // count in vmcnt on gfx950 and a predicated store is its own exec-masked block: behind a pending load the compiler waits
+  // vmcnt(0) - for the PREVIOUS STORE's completion - in every such block, 12 store round trips per lane.)
+  int rq[4];  // this lane's four realisation rows inside the group, clamped
+#pragma unroll
+  for (int g = 0; g < 4; ++g) rq[g] = min(quad + 4 * g, R - 1 - rb);
+  int jl4[4];  // GWB bracket indices of this lane's four TOAs: requested now, needed (as addresses) after the red-noise product
+#pragma unroll
+  for (int j = 0; j < 4; ++j) jl4[j] = pl.gw_npts > 0 ? pl.gw_jlo[start + min(tbase + 16 * j, count - 1)] : 0;
   pta_f64x4 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
@@ -231,51 +241,49 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
   const uint32_t strm_ec = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int ti = tbase + 16 * j;
-    if (ti >= count) continue;
-    const int i = start + ti;
+    const int i = start + min(tbase + 16 * j, count - 1);
+    // every per-TOA operand of this j is requested up front: a load issued between the Box-Muller chains is waited for on the
+    // spot (and, vmcnt being in-order, drags the stores of the previous j along)
+    const bool has_gw = pl.gw_npts > 0, has_wn = pl.wn_a != nullptr;
+    const double wgt = has_gw ? pl.gw_w[i] : 0.0;
+    pta_f64x2_a8 y[4];
+    if (has_gw) {  // GWB: both bracket samples of the mixed grid series in one 16-byte load (red_noise.py:286-287)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        y[g] = *reinterpret_cast<const pta_f64x2_a8 *>(pl.gw_G + ((int64_t)(rb + rq[g]) * P + a) * pl.gw_npts + jl4[j]);
+    }
+    const double wa = has_wn ? pl.wn_a[i] : 0.0, wb = has_wn ? pl.wn_b[i] : 0.0;
+    const uint32_t pair = (uint32_t)pl.idx_in_psr[i];
+    const double ec = has_ec ? pl.ecorr_toa[i] : 0.0;
+    const int e = has_ec ? pl.epoch_of[i] : 0;
+    const double det = pl.det ? pl.det[i] : 0.0;
     double v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) v[g] = acc[j][g];
-    if (pl.gw_npts > 0) {  // GWB: interpolate the mixed grid series (red_noise.py:286-287)
-      const int jl = pl.gw_jlo[i];
-      const double wgt = pl.gw_w[i];
+    if (has_gw) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = min(rb + quad + 4 * g, R - 1);
-        const double *gp = pl.gw_G + ((int64_t)r * P + a) * pl.gw_npts;
-        const pta_f64x2_a8 y = *reinterpret_cast<const pta_f64x2_a8 *>(gp + jl);  // both bracket samples in one 16-byte load
-        v[g] = v[g] + ((y.y - y.x) * wgt + y.x);
-      }
+      for (int g = 0; g < 4; ++g) v[g] = v[g] + ((y[g].y - y[g].x) * wgt + y[g].x);
     }
-    if (pl.wn_a) {  // EFAC/EQUAD (white_noise.py:105-109)
-      const double wa = pl.wn_a[i], wb = pl.wn_b[i];
-      const uint32_t pair = (uint32_t)pl.idx_in_psr[i];
+    if (has_wn) {  // EFAC/EQUAD (white_noise.py:105-109)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         double z1, z2;
-        pta_normal_pair(seed, r0 + (uint64_t)(rb + quad + 4 * g), strm_wn, pair, z1, z2, fast);
+        pta_normal_pair(seed, r0 + (uint64_t)(rb + rq[g]), strm_wn, pair, z1, z2, fast);
         v[g] = v[g] + (wa * z1 + wb * z2);
       }
     }
     if (has_ec) {  // ECORR (white_noise.py:182)
-      const double ec = pl.ecorr_toa[i];
-      const int e = pl.epoch_of[i];
       if (epn > 0) {
         const int o = e - 2 * ep0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * zec[quad + 4 * g][o];
+        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * zec[rq[g]][o];
       } else if (ec != 0.0) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + quad + 4 * g), strm_ec, (uint32_t)e, fast);
+        for (int g = 0; g < 4; ++g) v[g] = v[g] + ec * pta_normal_single(seed, r0 + (uint64_t)(rb + rq[g]), strm_ec, (uint32_t)e, fast);
       }
     }
-    const double det = pl.det ? pl.det[i] : 0.0;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = rb + quad + 4 * g;
-      if (r < R) out[(int64_t)r * ld_out + i] = v[g] + det;
-    }
+    for (int g = 0; g < 4; ++g) out[(int64_t)(rb + rq[g]) * ld_out + i] = v[g] + det;
   }
 }
 
