@@ -34,6 +34,17 @@ void hc_uniform_pairs(uint64_t seed, uint64_t realisation, uint32_t stream, int 
   for (int p = 0; p < npairs; ++p) pta_uniform_pair(pta_philox_draw(seed, realisation, stream, (uint32_t)p), out[2 * p], out[2 * p + 1]);
 }
 
+// the two transcendentals of the Box-Muller transform: table-driven (product path) and polynomial (cross-check)
+void hc_neg2log(const double *u, int n, int poly, double *out) {
+  for (int i = 0; i < n; ++i) out[i] = poly ? pta_neg2log_poly(u[i]) : pta_neg2log(u[i]);
+}
+void hc_sincos_2pi(const double *u, int n, int poly, double *sn, double *cs) {
+  for (int i = 0; i < n; ++i) {
+    if (poly) pta_sincos_2pi_poly(u[i], sn[i], cs[i]);
+    else pta_sincos_2pi(u[i], sn[i], cs[i]);
+  }
+}
+
 uint32_t hc_stream_id(uint32_t kind, uint32_t pulsar) { return pta_stream_id(kind, pulsar); }
 
 void hc_orf_hd(const double *locs, int P, double *orf) {

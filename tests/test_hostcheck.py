@@ -61,6 +61,80 @@ def test_normals_match_numpy_twin(hc):
     assert u[0::2].min() > 0.0 and u[0::2].max() <= 1.0 and u[1::2].min() >= 0.0 and u[1::2].max() < 1.0
 
 
+def _ulps(got, ref):
+    """|got - ref| in units of the spacing of doubles at ref (ref: longdouble)"""
+    L = np.longdouble
+    r64 = ref.astype(np.float64)
+    sp = np.spacing(np.where(r64 == 0, np.finfo(np.float64).tiny, np.abs(r64))).astype(L)
+    return (np.abs(got.astype(L) - ref) / sp).astype(np.float64)
+
+
+def test_table_driven_neg2log_accuracy(hc):
+    """-2 ln u of the product path (128-entry table + degree-5 remainder, pta_rng.h) against an 80-bit evaluation: < 1.5 ulp
+    everywhere, including the interval boundaries of the table, the re-centring boundary (j = 52 | 53) and u -> 1, where the
+    result must stay accurate RELATIVE to itself (the Box-Muller radius goes to zero there)."""
+    L = np.longdouble
+    if np.finfo(L).nmant < 63:
+        pytest.skip("no 80-bit long double on this host")
+    rng = np.random.default_rng(5)
+    u = np.concatenate([
+        1.0 - rng.random(400000),                                   # (0, 1]
+        np.exp(-rng.uniform(0, 36, 100000)),                        # down to 2^-52
+        1.0 - np.exp(-rng.uniform(0, 36, 100000)),                  # up against 1
+        np.array([1.0, 1.0 - 2.0 ** -53, 1.0 - 2.0 ** -52, 0.5, 0.25, 2.0 ** -52, 2.0 ** -51, 0.70710678118654752, 0.7071067811865476]),
+        np.ldexp(1.0 + np.arange(0, 129) / 128.0, -1)[:-1],         # every table boundary, and one ulp either side of it
+        np.nextafter(np.ldexp(1.0 + np.arange(1, 128) / 128.0, -1), 0.0), np.nextafter(np.ldexp(1.0 + np.arange(0, 128) / 128.0, -1), 1.0),
+    ])
+    u = u[(u > 0) & (u <= 1)]
+    out = np.zeros_like(u); pol = np.zeros_like(u)
+    hc.hc_neg2log(_p(u, ctypes.c_double), len(u), 0, _p(out, ctypes.c_double))
+    hc.hc_neg2log(_p(u, ctypes.c_double), len(u), 1, _p(pol, ctypes.c_double))
+    ref = L(-2) * np.log(u.astype(L))
+    nz = u < 1.0
+    assert _ulps(out[nz], ref[nz]).max() < 1.5
+    assert _ulps(pol[nz], ref[nz]).max() < 1.5          # the polynomial cross-check is held to the same bar
+    assert abs(out[~nz]).max() < 1e-18                  # u = 1: zero up to the rounding of one table entry; the caller clamps before sqrt
+    assert np.all(out[nz] > 0)
+
+
+def test_table_driven_sincos_accuracy(hc):
+    """sin / cos(2 pi u) of the product path (32-entry table + Taylor remainder + rotation): within 4.5 ulp (the rotation sums two rounded products), |error| <= 2.3e-16
+    absolute, and exact zeros / ones at the quarter turns."""
+    L = np.longdouble
+    if np.finfo(L).nmant < 63:
+        pytest.skip("no 80-bit long double on this host")
+    rng = np.random.default_rng(6)
+    u = np.concatenate([rng.random(500000), np.arange(0, 64) / 64.0, np.nextafter(np.arange(1, 64) / 64.0, 0.0), np.nextafter(np.arange(0, 64) / 64.0, 1.0),
+                        np.array([1.0 - 2.0 ** -52, 2.0 ** -52, 0.5 - 2.0 ** -53, 0.25 + 2.0 ** -54])])
+    sn, cs = np.zeros_like(u), np.zeros_like(u)
+    hc.hc_sincos_2pi(_p(u, ctypes.c_double), len(u), 0, _p(sn, ctypes.c_double), _p(cs, ctypes.c_double))
+    # reference: exact reduction to the nearest quarter turn in double, remainder through the 80-bit libm
+    q = np.rint(4 * u); x = (u.astype(L) - L(0.25) * q.astype(L)) * (L(2) * np.arccos(L(-1)))
+    sr, cr = np.sin(x), np.cos(x); k = q.astype(np.int64) & 3
+    rs = np.choose(k, [sr, cr, -sr, -cr]); rc = np.choose(k, [cr, -sr, -cr, sr])
+    assert max(_ulps(sn, rs).max(), _ulps(cs, rc).max()) < 4.5
+    assert max(np.abs(sn.astype(L) - rs).max(), np.abs(cs.astype(L) - rc).max()) < 2.3e-16
+    for uq, s0, c0 in ((0.0, 0.0, 1.0), (0.25, 1.0, 0.0), (0.5, 0.0, -1.0), (0.75, -1.0, 0.0)):
+        i = int(np.where(u == uq)[0][0])
+        assert sn[i] == s0 and cs[i] == c0
+
+
+def test_deviates_within_a_few_ulp_of_an_80_bit_box_muller(hc):
+    L = np.longdouble
+    if np.finfo(L).nmant < 63:
+        pytest.skip("no 80-bit long double on this host")
+    seed, r, stream, npairs = 77, 5, philox_ref.stream_id(3, 11), 1 << 18
+    out = np.zeros(2 * npairs)
+    hc.hc_normal_pairs(ctypes.c_uint64(seed), ctypes.c_uint64(r), ctypes.c_uint32(stream), npairs, _p(out, ctypes.c_double))
+    u1, u2 = philox_ref.uniform_pairs(seed, r, stream, npairs)
+    rad = np.sqrt(L(-2) * np.log(u1.astype(L)))
+    q = np.rint(4 * u2); x = (u2.astype(L) - L(0.25) * q.astype(L)) * (L(2) * np.arccos(L(-1)))
+    sr, cr = np.sin(x), np.cos(x); k = q.astype(np.int64) & 3
+    s = np.choose(k, [sr, cr, -sr, -cr]); c = np.choose(k, [cr, -sr, -cr, sr])
+    e = np.maximum(_ulps(out[0::2], rad * c), _ulps(out[1::2], rad * s))
+    assert e.max() < 6.0 and np.quantile(e, 0.999) < 3.5
+
+
 def test_normals_are_standard_normal(hc):
     npairs = 200000
     out = np.zeros(2 * npairs)
