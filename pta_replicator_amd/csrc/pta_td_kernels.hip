@@ -125,21 +125,28 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
     for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
   const int kr = t >> 4, cq = t & 15;  // slab row (k) and column phase of this thread; columns cq + 16 j
   double ra[8], rb[8];
+  // every load unconditional, from a clamped (always valid) address: a bin beyond K enters with phi = 0, a row / column beyond N
+  // lands in a part of the tile that is never stored.  (Predicated, each of the 17 loads of a slab sat in its own exec-masked
+  // block behind an s_waitcnt vmcnt(0): 17 serialised L2 round trips per slab.)
+  // (the scaling by phi happens in stash(), after the MFMAs of the current slab: nothing consumes a load inside fetch())
+  double pk = 0.0;
+  bool pk_in = false;
   auto fetch = [&](int k0) {
-    const int gk = k0 + kr;
-    const bool kin = gk < K;
-    const double p = kin ? ph[gk] : 0.0;
+    const int gk = k0 + kr, gkc = min(gk, K - 1);
+    pk = ph[gkc];
+    pk_in = gk < K;
+    const double *__restrict__ Fk = F + (int64_t)gkc * ldf;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int gi = m0 + cq + 16 * j, gj = n0 + cq + 16 * j;
-      ra[j] = (kin && gi < N) ? p * F[(int64_t)gk * ldf + gi] : 0.0;
-      rb[j] = (kin && gj < N) ? F[(int64_t)gk * ldf + gj] : 0.0;
+      ra[j] = Fk[min(m0 + cq + 16 * j, N - 1)];
+      rb[j] = Fk[min(n0 + cq + 16 * j, N - 1)];
     }
   };
   auto stash = [&](int buf) {
+    const double p = pk_in ? pk : 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      As[buf][kr][cq + 16 * j] = ra[j];
+      As[buf][kr][cq + 16 * j] = p * ra[j];
       Bs[buf][kr][cq + 16 * j] = rb[j];
     }
   };
@@ -183,19 +190,31 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
     const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
     ecol[j] = (epoch_of && col < N) ? epoch_of[off + col] : -1;
   }
+  // the diagonal (white) term exists only in diagonal tiles and the ECORR block only where an epoch of the rows meets the same
+  // epoch among the columns; both vectors are read for all 16 rows of the lane in one go (clamped addresses), then added by
+  // selects - no load sits behind a per-element predicate
+  const bool diag_tile = (bm == bn);  // workgroup-uniform
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    double s2[4], e2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rowc = min(m0 + wm * 64 + i * 16 + pta_mfma_row(l, r), N - 1);
+      s2[r] = diag_tile ? sigma2[off + rowc] : 0.0;
+      e2[r] = epoch_of ? ecorr2[off + rowc] : 0.0;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
-      if (row >= N) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
-        if (row == col) acc[i][j][r] = acc[i][j][r] + sigma2[off + row];
-        if (col <= row && erow[i][r] == ecol[j]) acc[i][j][r] = acc[i][j][r] + ecorr2[off + row];
+        double add = (row == col) ? s2[r] : 0.0;
+        if (col <= row && erow[i][r] == ecol[j]) add += e2[r];
+        acc[i][j][r] = acc[i][j][r] + add;
       }
     }
+  }
   constexpr int SLD = TC_T + 4;                      // staging pitch (doubles): 64 x 132 x 8 B = 67.6 KB <= the 73.7 KB of slabs
   double (*S)[SLD] = reinterpret_cast<double (*)[SLD]>(smem);
 #pragma unroll
@@ -215,8 +234,10 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
       const int col = n0 + 2 * l;
       const double2 v = *reinterpret_cast<const double2 *>(&S[rr][2 * l]);
       double *__restrict__ dst = C + (int64_t)row * ldc + col;
-      if (col + 1 <= row)
+      if (!diag_tile)                                    // strictly below the diagonal: every column of the row is stored
         *reinterpret_cast<double2 *>(dst) = v;          // ldc and n0 are even, the block base 16-byte aligned
+      else if (col + 1 <= row)
+        *reinterpret_cast<double2 *>(dst) = v;
       else if (col == row)
         dst[0] = v.x;
     }
