@@ -58,31 +58,39 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
   }
 
   for (int k0 = 0; k0 < K; k0 += GBK) {
+    // slab loads: unconditional, from clamped (always valid) addresses, all issued before the first select - predicated, each
+    // load sits in its own exec-masked block and is waited for on its own
+    double la[4], lb[4];
     {  // A slab: 64 rows x 16 k, 4 consecutive k per thread
-      int row = t >> 2, kq = (t & 3) * 4;
-      int gm = m0 + row;
+      const int gm = min(m0 + (t >> 2), M - 1), kq = (t & 3) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int gk = k0 + kq + j;
-        As[kq + j][row] = (gm < M && gk < K) ? A[(int64_t)gm * lda + (int64_t)gk * ska] : 0.0;
-      }
+      for (int j = 0; j < 4; ++j) la[j] = A[(int64_t)gm * lda + (int64_t)min(k0 + kq + j, K - 1) * ska];
     }
     if (BT) {  // B given as [N x K]: element (k, n) at B[n*ldb + k]
-      int col = t >> 2, kq = (t & 3) * 4;
-      int gn = n0 + col;
+      const int gn = min(n0 + (t >> 2), N - 1), kq = (t & 3) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int gk = k0 + kq + j;
-        Bs[kq + j][col] = (gn < N && gk < K) ? B[(int64_t)gn * ldb + gk] : 0.0;
-      }
+      for (int j = 0; j < 4; ++j) lb[j] = B[(int64_t)gn * ldb + min(k0 + kq + j, K - 1)];
     } else {  // B given as [K x N]: coalesced along n
-      int kr = t >> 4, nq = (t & 15) * 4;
-      int gk = k0 + kr;
+      const int gk = min(k0 + (t >> 4), K - 1), nq = (t & 15) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int gn = n0 + nq + j;
-        Bs[kr][nq + j] = (gk < K && gn < N) ? B[(int64_t)gk * ldb + gn] : 0.0;
-      }
+      for (int j = 0; j < 4; ++j) lb[j] = B[(int64_t)gk * ldb + min(n0 + nq + j, N - 1)];
+    }
+    {
+      const int row = t >> 2, kq = (t & 3) * 4;
+      const bool rin = m0 + row < M;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[kq + j][row] = (rin && k0 + kq + j < K) ? la[j] : 0.0;
+    }
+    if (BT) {
+      const int col = t >> 2, kq = (t & 3) * 4;
+      const bool cin = n0 + col < N;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[kq + j][col] = (cin && k0 + kq + j < K) ? lb[j] : 0.0;
+    } else {
+      const int kr = t >> 4, nq = (t & 15) * 4;
+      const bool kin = k0 + kr < K;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Bs[kr][nq + j] = (kin && n0 + nq + j < N) ? lb[j] : 0.0;
     }
     __syncthreads();
 #pragma unroll

@@ -86,12 +86,22 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n
   double *M = A + (int64_t)blockIdx.x * sA + (int64_t)k0 * n + k0;  // n = row pitch (lda)
   const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
   double v[4][4];
+  // all 16 loads first, unconditional, from clamped addresses; the selects follow (predicated, or consumed one by one, each load
+  // is waited for on its own: 16 serial round trips at the head of a kernel that runs one workgroup per matrix)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pc = min(ti + 16 * a, nb - 1);
+      v[a][b] = M[(int64_t)pc * n + min(tc + 16 * b, pc)];
+    }
+  asm volatile("" ::: "memory");  // keep the loads together: nothing below may be scheduled between them
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int p = ti + 16 * a, q = tc + 16 * b;
-      v[a][b] = (p < nb && q <= p) ? M[(int64_t)p * n + q] : 0.0;
+      v[a][b] = (p < nb && q <= p) ? v[a][b] : 0.0;
     }
 #pragma unroll
   for (int jq = 0; jq < 4; ++jq) {
