@@ -107,8 +107,8 @@ def src_sha(*files):
 
 
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
-SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_mfma.h")
-TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_mfma.h")
+SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
+TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 
 
 def pmc_entry(key, srcs, **shape):
