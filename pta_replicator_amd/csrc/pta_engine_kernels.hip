@@ -139,8 +139,7 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, MINW) void k_engine_synth(pta_engi
 
 // MFMA variant (default).  The ablation of the VALU kernel above (profiles/) shows the red-noise F @ y loop as its largest
 // single term (1.5 of 4.1 ms at 68 x 5000, R = 960): 60 dependent scalar-load + FMA steps per TOA.  F @ y for a tile IS a small
-// dense product - [16 realisations x 60] . [60 x 256 TOAs] - so it goes to the matrix pipe (same fp64 ALUs as v_fma_f64 on gfx950,
-// what the MFMA form saves is issue slots, scalar loads and register traffic, not ALU time):
+// dense product - [16 realisations x 60] . [60 x 256 TOAs] - so it goes to the otherwise idle matrix cores:
 // one wave = 16 realisations x 64 TOAs = 4 tiles of v_mfma_f64_16x16x4_f64, 15 K-steps; lane l supplies the coefficient of
 // realisation (l & 15), bin (l >> 4) and the design-matrix entry of bin (l >> 4), TOA (l & 15) of each tile, and receives the
 // sums for realisations (l >> 4) + 4 g, TOA (l & 15): exactly the (4 TOAs x 4 realisations) it then finishes on the VALU
