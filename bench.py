@@ -109,6 +109,7 @@ def src_sha(*files):
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
 SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
+CZT_SRC = ("pta_czt_kernels.hip", "pta_fft.h", "pta_rng.h", "pta_rng_tables.h")
 
 
 def pmc_entry(key, srcs, **shape):
@@ -390,9 +391,21 @@ def main():
     def flop_roof(k):
         ach = alg_flops_gwb / (kern[k] * 1e-3) / 1e12
         bound = "mfma" if k == "pta_gwb_idft_rng" else "valu-fp64"
-        return {"kernel": k, "bound": bound, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12,
-                "avg_launch_ms": kern[k]}
+        d = {"kernel": k, "bound": bound, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12,
+             "avg_launch_ms": kern[k]}
+        if k == "pta_gwb_czt":
+            e, why = pmc_entry("k_gwb_czt<true, false, 15>", CZT_SRC, rows=R * P)
+            if e:
+                d["traffic"] = (e["fetch_kib"] + e["write_kib"]) * 1024.0
+                d["traffic_source"] = e.get("source")
+                if e.get("insts_valu"):
+                    issue_ms = e["insts_valu"] * 4.0 / (256 * 4) / 2.4e9 * 1e3
+                    d["valu_issue"] = {"insts_valu": e["insts_valu"], "insts_valu_per_row": e["insts_valu"] * 64.0 / (R * P),
+                                       "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k], "valu_busy_pmc": e.get("valu_busy")}
+            else:
+                d["traffic_note"] = why
+        return d
 
     if kern["pta_engine_synth"] >= kern[gwb_kernel]:
         roof, other = hbm_roof("pta_engine_synth"), flop_roof(gwb_kernel)

@@ -3,7 +3,7 @@
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import SYNTH_SRC, TD_SRC, src_sha
+from bench import CZT_SRC, SYNTH_SRC, TD_SRC, src_sha
 
 out_dir, R, n_toa, n_psr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 
@@ -48,6 +48,22 @@ if nf and nw:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE"):
             e["valu_busy"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD) if a.get("SQ_ACTIVE_INST_VALU") else None
+            e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
+    res[k] = e
+# ---- chirp-z kernel of the GWB stage (default variant, fp64 transform): one workgroup per (realisation, pulsar) row
+k = "k_gwb_czt<true, false, 15>"
+f, nf = sums("pmc_fetch", k)
+w, nw = sums("pmc_write", k)
+a, na = sums("pmc_sq", k)
+ms, nt = avg_ms(k)
+if nf and nw:
+    e = {"rows": R * n_psr, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
+         "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*CZT_SRC),
+         "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
+    if na:
+        e["insts_valu"] = a.get("SQ_INSTS_VALU")
+        if a.get("GRBM_GUI_ACTIVE") and a.get("SQ_ACTIVE_INST_VALU"):
+            e["valu_busy"] = a["SQ_ACTIVE_INST_VALU"] * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD)
             e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
     res[k] = e
 # ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches
