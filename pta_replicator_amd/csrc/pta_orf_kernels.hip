@@ -180,12 +180,14 @@ __global__ __launch_bounds__(256) void k_trsm(double *__restrict__ A, int nrow, 
     for (int c = t & 63; c < nb; c += 64) M[(int64_t)(r0 + i) * n + (k0 + c)] = X[i][c];
 }
 
-// Panel solve on the matrix cores: X <- X L11^{-T} = X . Linv^T, 64 rows per workgroup, K = 64.
-// Both operands sit row-major ("m-major") in LDS with an odd pitch, so the 16-lane fragment reads (one row each)
-// fall on distinct banks and the tile loads need no transposition.
+// Panel solve on the matrix cores: X <- X L11^{-T} = X . Linv^T, K = 64, one 16-row block of X per wave and step.
+// The sum over k is order independent, so the four k-slots of a v_mfma_f64_16x16x4 step t are given the columns k = 16 q + t
+// (q = lane >> 4) instead of 4 t + q: a lane's sixteen A elements are then 128 CONTIGUOUS bytes of its own row - X goes from
+// global memory straight into registers (eight 16-byte loads), needs no LDS and no barrier, and the wave writes its 16 x 64
+// result back in place before it moves on.  The inverted diagonal block is staged once per workgroup (transposed into LDS as
+// k_potf2 parked it) and its B fragments - Linv[16 j + n][16 q + t] - are kept in registers for every block the wave walks.
 __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int nrow, int64_t n, int64_t sA, int k0, int nb) {
   __shared__ double Li[CH_NB][CH_LD];  // Li[c][t] = (L11^{-1})[c][t], zero for t > c
-  __shared__ double X[CH_NB][CH_LD];
   double *M = A + (int64_t)blockIdx.y * sA;
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   for (int i = t >> 6; i < CH_NB; i += 4)
@@ -200,43 +202,50 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
       }
       Li[c][i] = v;
     }
-  const int wm = w >> 1, wn = w & 1;
-  const int nblk = (nrow - k0 - nb + CH_NB - 1) / CH_NB;
-  // grid-stride over the 64-row blocks below the diagonal block: the inverse is staged once per workgroup, not once per block
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int r0 = k0 + nb + blk * CH_NB;
-    const int rows = min(CH_NB, nrow - r0);
-    for (int i = t >> 6; i < CH_NB; i += 4)
-      for (int c = t & 63; c < CH_NB; c += 64) X[i][c] = (i < rows && c < nb) ? M[(int64_t)(r0 + i) * n + (k0 + c)] : 0.0;
-    __syncthreads();
-    pta_f64x4 acc[2][2];
+  __syncthreads();
+  const int q = l >> 4, c = l & 15;
+  double bq[4][16];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int kk = 0; kk < CH_NB; kk += 4) {
-      double a[2], b[2];
+    for (int s = 0; s < 16; ++s) bq[j][s] = Li[j * 16 + c][16 * q + s];
+  typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // k0 may be odd: 8-byte alignment only
+  const int r0 = k0 + nb;
+  const int nblk = (nrow - r0 + 15) >> 4;
+  // every 16-byte load of a row stays inside the block's nb columns (nb < 64 only for the first, narrow block)
+  const int kq = 16 * q;
+  for (int blk = blockIdx.x * 4 + w; blk < nblk; blk += gridDim.x * 4) {
+    const int row = min(r0 + blk * 16 + c, nrow - 1);  // rows past the end recompute the last one; their results are not stored
+    const double *__restrict__ xr = M + (int64_t)row * n + k0;
+    double a[16];
+    if (nb >= 2) {  // workgroup-uniform.  A pair that would straddle the block's last column (odd nb) is read one column early
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = X[wm * 32 + i * 16 + (l & 15)][kk + (l >> 4)];
+      for (int h = 0; h < 8; ++h) {
+        const int k = kq + 2 * h;
+        const f64x2_a8 v = *reinterpret_cast<const f64x2_a8 *>(xr + min(k, nb - 2));
+        a[2 * h] = (k + 1 < nb) ? v.x : ((k < nb) ? v.y : 0.0);
+        a[2 * h + 1] = (k + 1 < nb) ? v.y : 0.0;
+      }
+    } else {
+      const double x0 = xr[0];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = Li[wn * 32 + j * 16 + (l & 15)][kk + (l >> 4)];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
+      for (int s = 0; s < 16; ++s) a[s] = 0.0;
+      a[0] = (kq == 0) ? x0 : 0.0;
     }
+    pta_f64x4 acc[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 4; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+    for (int s = 0; s < 16; ++s)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          int row = wm * 32 + i * 16 + pta_mfma_row(l, r);
-          int col = wn * 32 + j * 16 + pta_mfma_col(l);
-          if (row < rows && col < nb) M[(int64_t)(r0 + row) * n + (k0 + col)] = acc[i][j][r];
-        }
-    __syncthreads();  // every wave is done with X before the next block overwrites it
+      for (int j = 0; j < 4; ++j) acc[j] = pta_mfma_f64(a[s], bq[j][s], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = r0 + blk * 16 + pta_mfma_row(l, r), ocol = j * 16 + pta_mfma_col(l);
+        if (orow < nrow && ocol < nb) M[(int64_t)orow * n + (k0 + ocol)] = acc[j][r];
+      }
   }
 }
 
@@ -285,7 +294,7 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
     const int rows = n - c0 - w;
     if (rows <= 0) return PTA_OK;
     if (algo && !(flags & PTA_POTRF_SUBSTITUTION)) {
-      // about 1024 workgroups per launch (2 resident per CU x 2 rounds), each walking its share of the row blocks
+      // about 1024 workgroups per launch (2 resident per CU x 2 rounds), each wave walking its share of the 16-row blocks
       const int nblk = pta_cdiv(rows, CH_NB), per = pta_cdiv(1024, B);
       hipLaunchKernelGGL(k_trsm_mfma, dim3(nblk < per ? nblk : per, B), dim3(256), 0, sp, A, n, lda, sA, c0, w);
     }

@@ -155,7 +155,8 @@ def test_orf_kernels_vs_reference_golden(gpu):
     assert np.max(np.abs(orf2 - 2 * sum(clm[k] * ref[k] for k in range(4)))) < 1e-13
 
 
-@pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (64, 1), (68, 1), (130, 4), (200, 2), (515, 1), (512, 2), (1000, 1), (1338, 3)])
+@pytest.mark.parametrize("n,batch", [(1, 1), (3, 2), (64, 1), (65, 2), (68, 1), (130, 4), (131, 1), (200, 2), (515, 1), (512, 2), (1000, 1), (1001, 1), (1025, 2),
+                                     (1338, 3)])   # 65 / 1025: a first block 1 column wide; 131 / 1001: odd widths (3, 41)
 def test_potrf_batched_vs_numpy(gpu, n, batch):
     from pta_replicator_amd import red_noise as rn
     dv, lib = gpu["dv"], gpu["lib"]
