@@ -249,6 +249,61 @@ __global__ __launch_bounds__(256) void k_trsm_mfma(double *__restrict__ A, int n
   }
 }
 
+// The K = 64 update inside a 128-column group, A22[:, 0:64] -= L21 . L21[0:64, :]^T (lower triangle), with the operand scheme of
+// k_trsm_mfma: both operands are rows of the panel just solved, 128 contiguous bytes per lane, straight from global memory into
+// MFMA registers - no LDS at all.  The multiplier rows (the 64 rows right below the diagonal block) stay in registers for every
+// 16-row block the wave walks; C is read 16 elements at a time from clamped addresses, only the stores are predicated.
+__global__ __launch_bounds__(256) void k_syrk64(double *__restrict__ A, int nrow, int64_t n, int64_t sA, int c0) {
+  double *M = A + (int64_t)blockIdx.y * sA;
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int q = l >> 4, c = l & 15;
+  typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+  const int r0 = c0 + CH_NB;           // first row below the diagonal block = first row AND first column of A22
+  double bq[4][16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int br = r0 + 16 * j + c;    // multiplier row; past the end of the matrix it contributes nothing that is stored
+    const double *__restrict__ p = M + (int64_t)min(br, nrow - 1) * n + c0 + 16 * q;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const f64x2_a8 v = *reinterpret_cast<const f64x2_a8 *>(p + 2 * h);
+      bq[j][2 * h] = v.x;
+      bq[j][2 * h + 1] = v.y;
+    }
+  }
+  const int nblk = (nrow - r0 + 15) >> 4;
+  for (int blk = blockIdx.x * 4 + w; blk < nblk; blk += gridDim.x * 4) {
+    const double *__restrict__ xr = M + (int64_t)min(r0 + blk * 16 + c, nrow - 1) * n + c0 + 16 * q;
+    double a[16];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const f64x2_a8 v = *reinterpret_cast<const f64x2_a8 *>(xr + 2 * h);
+      a[2 * h] = v.x;
+      a[2 * h + 1] = v.y;
+    }
+    const int orow0 = r0 + blk * 16 + (l >> 4), ocol0 = r0 + c;  // + 4 r, + 16 j
+    double cv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cv[j][r] = M[(int64_t)min(orow0 + 4 * r, nrow - 1) * n + min(ocol0 + 16 * j, nrow - 1)];
+    pta_f64x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = pta_mfma_f64(a[s], bq[j][s], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = orow0 + 4 * r, ocol = ocol0 + 16 * j;
+        if (orow < nrow && ocol <= orow) M[(int64_t)orow * n + ocol] = cv[j][r] - acc[j][r];
+      }
+  }
+}
+
 __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t sA) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   int r = blockIdx.y;
@@ -314,8 +369,14 @@ static int pta_factor_panel(double *A, int n, int64_t lda, int64_t sA, int B, in
   const int rows = n - (c0 + w1);
   const double *L21 = A + (int64_t)(c0 + w1) * lda + c0;
   double *A22 = A + (int64_t)(c0 + w1) * lda + (c0 + w1);
-  rc = pta_dgemm_launch(1, rows, cols, w1, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, sA, sA, sA, algo, sp);
-  if (rc != PTA_OK) return rc;
+  if (algo && w1 == CH_NB && cols == CH_NB) {  // the K = 64 update of a 128-column group: register-operand kernel, no LDS
+    const int per = pta_cdiv(1024, B), nb64 = pta_cdiv(rows, CH_NB);
+    hipLaunchKernelGGL(k_syrk64, dim3(nb64 < per ? nb64 : per, B), dim3(256), 0, sp, A, n, lda, sA, c0);
+    PTA_LAUNCH_CHECK();
+  } else {
+    rc = pta_dgemm_launch(1, rows, cols, w1, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, sA, sA, sA, algo, sp);
+    if (rc != PTA_OK) return rc;
+  }
   return pta_factor_panel(A, n, lda, sA, B, c0 + w1, cols, info, flags, algo, sp);
 }
 
