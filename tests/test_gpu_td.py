@@ -129,9 +129,12 @@ def _small_array(with_gwb, with_cgw=False, seed=21):
     return eng, psrs, noise
 
 
-def _oracle_covariances(eng, psrs, noise, components=12):
+def _oracle_covariances(eng, psrs, noise, components=12, only=None):
     covs = []
     for a, psr in enumerate(psrs):
+        if only is not None and a != only:
+            covs.append(None)
+            continue
         n = int(eng.counts[a])
         tf = np.array([f["f"] for f in psr.toas.table["flags"].data])
         sig = eng.sigma_s[a]
@@ -308,6 +311,26 @@ def test_td_headline_size_vs_numpy():
               ctypes.c_void_p(ec2.data_ptr() + 8 * o), dv.ptr(Cd), n, dv.stream_ptr())
     il = np.tril_indices(n)
     assert np.max(np.abs(Cd.cpu().numpy()[il] - covs[a][il])) < 1e-10 * np.max(np.abs(covs[a]))
+
+
+def test_td_config5_size_one_pulsar_vs_lapack():
+    """N = 10 000 TOAs (BASELINE.json config 5's per-pulsar size; 10000 mod 128 = 16, so the first panel is 1040 wide), three
+    pulsars with ng15 noise values: the factor of one pulsar against LAPACK and L.z against NumPy at 1e-10."""
+    from pta_replicator_amd.engine import ReplicaEngine
+    from bench import configure_engine, headline_array
+    psrs, noise = headline_array(3, 10000)
+    eng = configure_engine(ReplicaEngine(psrs, seed=55), noise)
+    eng._gw = None
+    eng.prepare_td()
+    out = eng.generate_td(2).cpu().numpy()
+    a = 1
+    cov = _oracle_covariances(eng, psrs, noise, components=30, only=a)[a]
+    Lref = np.linalg.cholesky(cov)
+    L = eng.td_factor(a).cpu().numpy()
+    assert np.max(np.abs(L - Lref)) < 1e-10 * np.max(np.abs(Lref))
+    sl = slice(eng.off[a], eng.off[a + 1])
+    for r in range(2):
+        assert relrms(out[r, sl], Lref @ eng.dump_draws_td(r)["td"][a]) < 1e-10, r
 
 
 def test_td_engine_fast_rng_math_is_self_consistent():
