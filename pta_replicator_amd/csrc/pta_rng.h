@@ -211,7 +211,8 @@ PTA_HD void pta_sincos_2pi_poly(double u, double &sn, double &cs) {
 //    ~25 instructions against 38 for the fdlibm-style evaluation above (no division, no degree-14 polynomial).
 //  sin / cos(2 pi u): nearest 32nd of a turn from the table (exact zeros at the quarter turns), remainder |x| <= pi / 32 through
 //    the Taylor series to x^9 / x^8 (truncation < 3e-17), one rotation: ~23 instructions against 37 (no quadrant selects).
-// Accuracy (scripts/gpu_rng_accuracy.py): every deviate within 4 ulp of an 80-bit evaluation of the same uniforms.
+// Accuracy (tests/test_hostcheck.py, scripts/gpu_rng_accuracy.py): -2 ln u within 1.5 ulp, sin / cos within 4.5 ulp (the rotation sums
+// two rounded products) and 2.3e-16 absolute, every deviate within 5 ulp of an 80-bit evaluation of the same uniforms (99.9 %: 2.7).
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double *pta_rng_lds() {
   __shared__ double __attribute__((aligned(16))) tab[PTA_RNG_TAB_DOUBLES];
