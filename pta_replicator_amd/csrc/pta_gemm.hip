@@ -231,6 +231,12 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
   fetch(0);
   stash(0);
   __syncthreads();
+  double fa[4], fb[4];  // fragments of the first K-step of the slab about to be consumed
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    fa[i] = As[0][l >> 4][wm * 64 + i * 16 + (l & 15)];
+    fb[i] = Bs[0][l >> 4][wn * 64 + i * 16 + (l & 15)];
+  }
   const int nslab = (K + GBK - 1) / GBK;
   for (int sidx = 0; sidx < nslab; ++sidx) {
     const int cur = sidx & 1;
@@ -239,10 +245,15 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
 #pragma unroll
     for (int kk = 0; kk < GBK; kk += 4) {
       double a[4], b[4];
+      if (kk == 0) {  // read right behind the previous iteration's barrier (fa / fb below)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[cur][kk + (l >> 4)][wm * 64 + i * 16 + (l & 15)];
+        for (int i = 0; i < 4; ++i) a[i] = fa[i], b[i] = fb[i];
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kk + (l >> 4)][wn * 64 + j * 16 + (l & 15)];
+        for (int i = 0; i < 4; ++i) a[i] = As[cur][kk + (l >> 4)][wm * 64 + i * 16 + (l & 15)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kk + (l >> 4)][wn * 64 + j * 16 + (l & 15)];
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -250,6 +261,13 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
     }
     stash(cur ^ 1);
     __syncthreads();
+    // the first fragments of the slab just published are requested HERE, in front of whatever MFMAs of this iteration the
+    // compiler sinks below the barrier, instead of at the top of the next iteration behind its address arithmetic and loads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i] = As[cur ^ 1][l >> 4][wm * 64 + i * 16 + (l & 15)];
+      fb[i] = Bs[cur ^ 1][l >> 4][wn * 64 + i * 16 + (l & 15)];
+    }
   }
   // epilogue: C = alpha acc + beta C.  The read of C is the kernel's one dependent HBM round trip after the last MFMA
   // (measured with beta = 0: it costs 10 % at K = 1024, 17 % at 512, 35 % at 256 when done element by element), so the 16
