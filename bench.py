@@ -323,16 +323,17 @@ def main():
 
     def gather_phase(line):
         """N > 1: the north_star's gather of the residual arrays to rank 0, pipelined with generation.  Runs LAST and under a
-        watchdog: the multi-GPU path cannot be exercised on the 1-GPU development box, so if it were to hang, rank 0 still
+        60 s watchdog: the RCCL path cannot be exercised on the 1-GPU development box (two ranks on one device over gloo move
+        CUDA tensors at ~50 MB/s: scripts/gpu_gather_debug.py checks the logic there at a reduced width), so if it were to hang, rank 0 still
         prints the line it has (without the gather figure) and every rank exits."""
         import threading
 
         def bail():
             if rank == 0:
-                line["gathered_to_rank0"] = {"error": "timed out after 180 s (watchdog)"}
+                line["gathered_to_rank0"] = {"error": "timed out after 60 s (watchdog)"}
                 print(json.dumps(line), flush=True)
             os._exit(0)
-        dog = threading.Timer(180.0, bail)
+        dog = threading.Timer(60.0, bail)
         dog.daemon = True
         dog.start()
         try:
