@@ -239,11 +239,16 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
   }
   const uint32_t strm_wn = pta_stream_id(PTA_STREAM_WN, (uint32_t)a);
   const uint32_t strm_ec = pta_stream_id(PTA_STREAM_ECORR, (uint32_t)a);
+  // Loads and stores share the in-order vmcnt on gfx950: waiting for a load also waits for every store issued before it.  The four
+  // stores of iteration j are therefore issued one iteration late, BEHIND the operand loads of iteration j + 1 - they then drain
+  // under that iteration's Box-Muller chains instead of in front of its first use of a loaded value.
+  double pend[4] = {0.0, 0.0, 0.0, 0.0};
+  int pend_i = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int i = start + min(tbase + 16 * j, count - 1);
     // every per-TOA operand of this j is requested up front: a load issued between the Box-Muller chains is waited for on the
-    // spot (and, vmcnt being in-order, drags the stores of the previous j along)
+    // spot
     const bool has_gw = pl.gw_npts > 0, has_wn = pl.wn_a != nullptr;
     const double wgt = has_gw ? pl.gw_w[i] : 0.0;
     pta_f64x2_a8 y[4];
@@ -257,6 +262,10 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
     const double ec = has_ec ? pl.ecorr_toa[i] : 0.0;
     const int e = has_ec ? pl.epoch_of[i] : 0;
     const double det = pl.det ? pl.det[i] : 0.0;
+    if (j > 0) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(int64_t)(rb + rq[g]) * ld_out + pend_i] = pend[g];
+    }
     double v[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) v[g] = acc[j][g];
@@ -283,8 +292,11 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, 4) void k_engine_synth_mfma(pta_en
       }
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) out[(int64_t)(rb + rq[g]) * ld_out + i] = v[g] + det;
+    for (int g = 0; g < 4; ++g) pend[g] = v[g] + det;
+    pend_i = i;
   }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) out[(int64_t)(rb + rq[g]) * ld_out + pend_i] = pend[g];
 }
 
 extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed, uint64_t r0, int R, double *out, int64_t ld_out,
