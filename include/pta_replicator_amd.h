@@ -94,6 +94,14 @@ int pta_wn(const double *sigma, const double *efac, const double *equad, int N, 
 int pta_quantize_epochs(const double *times_host, int N, double dt, const int64_t *order_host,
                         int32_t *epoch_of_host, int32_t *first_index_host, int *n_epochs);
 
+/* HOST helper of the CW-catalogue path: out_host[i] = x_host[3i .. 3i+2] . y_host[0..2], summed as fma(x2, y2, fma(x1, y1, x0 * y0)) -
+ * the association np.dot (OpenBLAS ddot) uses for the antenna-pattern dot products of deterministic.py:364-372, so that the
+ * per-source scalars of a whole catalogue are bit-identical to the reference's per-source loop without a Python-level loop.   */
+int pta_dot3_host(const double *x_host, int64_t n, const double *y_host, double *out_host);
+/* out_host[i] = pow(x_host[i], y) through libm's scalar pow (what the reference's per-source scalar expressions evaluate to;
+ * NumPy's array power differs from it by an ulp on a few per cent of arguments).                                        */
+int pta_pow_host(const double *x_host, double y, int64_t n, double *out_host);
+
 /* out[r,i] (+)= ecorr_epoch[epoch_of[i]] * z[r*ld_z + epoch_of[i]]
  * Replaces dt = (U*ecorrvec) @ randn(E) (white_noise.py:182): a gather, not an N x E matvec. */
 int pta_ecorr(const int32_t *epoch_of, const double *ecorr_epoch, int N, int E, const double *z, int64_t ld_z, int R,

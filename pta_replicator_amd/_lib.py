@@ -70,6 +70,8 @@ _SIGNATURES = {
     "pta_rn_synth": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_wn": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_quantize_epochs": (c_int, [_P, c_int, c_double, _P, _P, _P, POINTER(c_int)]),
+    "pta_dot3_host": (c_int, [_P, c_int64, _P, _P]),
+    "pta_pow_host": (c_int, [_P, c_double, c_int64, _P]),
     "pta_ecorr": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_orf_hd": (c_int, [_P, c_int, _P, _P]),
     "pta_orf_basis": (c_int, [_P, _P, c_int, c_int, _P, _P]),

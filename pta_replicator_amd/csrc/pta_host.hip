@@ -61,3 +61,29 @@ extern "C" int pta_quantize_epochs(const double *times_host, int N, double dt, c
   *n_epochs = e + 1;
   return PTA_OK;
 }
+
+// out[i] = fma(x[i][2], y[2], fma(x[i][1], y[1], x[i][0] * y[0])): the three-term dot product in the association OpenBLAS' ddot
+// (= np.dot on two 3-vectors, the call at deterministic.py:364-372 inside the reference's per-source loop) uses on x86-64 -
+// verified against np.dot by the Python caller on every catalogue before it trusts this routine.  Lets cw_source_params
+// evaluate F+, Fx and cos(mu) of a whole catalogue without a Python-level loop while staying bit-identical to the reference.
+extern "C" int pta_dot3_host(const double *x_host, int64_t n, const double *y_host, double *out_host) {
+  PTA_REQUIRE(x_host && y_host && out_host, PTA_E_ARG, "pta_dot3_host: NULL argument");
+  PTA_REQUIRE(n >= 0, PTA_E_ARG, "pta_dot3_host: n=%lld", (long long)n);
+  const double y0 = y_host[0], y1 = y_host[1], y2 = y_host[2];
+  for (int64_t i = 0; i < n; ++i) {
+    const double *x = x_host + 3 * i;
+    const double p0 = x[0] * y0;  // a rounded product (-ffp-contract=off: never fused with what follows)
+    out_host[i] = fma(x[2], y2, fma(x[1], y1, p0));
+  }
+  return PTA_OK;
+}
+
+// out[i] = pow(x[i], y) through the C library's scalar pow - what a NumPy float64 SCALAR `x ** y` (the reference's per-source loop
+// body, deterministic.py:340-383) and numba's compiled loops call; NumPy's ARRAY power uses its own SIMD kernels, which differ from
+// libm by an ulp on ~5 % of arguments (measured), enough to move the evolving-CW phase offsets by 1e-7 relative.
+extern "C" int pta_pow_host(const double *x_host, double y, int64_t n, double *out_host) {
+  PTA_REQUIRE(x_host && out_host, PTA_E_ARG, "pta_pow_host: NULL argument");
+  PTA_REQUIRE(n >= 0, PTA_E_ARG, "pta_pow_host: n=%lld", (long long)n);
+  for (int64_t i = 0; i < n; ++i) out_host[i] = pow(x_host[i], y);
+  return PTA_OK;
+}

@@ -311,26 +311,30 @@ __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t
 }
 
 
-// Internal streams + events of the chained schedule below, created on first use for the calling thread's current device.
+// Internal streams + events of the chained schedule below, created on first use, one context per (calling thread, device): a
+// process that alternates devices keeps every device's handles (a single context recreated - and leaked - its four
+// streams and five events whenever the current device changed).
 #define PTA_POTRF_MAX_CHAINS 4
+#define PTA_POTRF_MAX_DEVICES 16
 struct pta_potrf_ctx {
-  int dev = -1;
+  bool ready = false;
   hipStream_t chain[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_in = nullptr, ev_out[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
 };
-static thread_local pta_potrf_ctx g_potrf_ctx;
+static thread_local pta_potrf_ctx g_potrf_ctx[PTA_POTRF_MAX_DEVICES];
 
 static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
   int dev = 0;
   PTA_HIP(hipGetDevice(&dev));
-  pta_potrf_ctx &c = g_potrf_ctx;
-  if (c.dev != dev) {
+  PTA_REQUIRE(dev >= 0 && dev < PTA_POTRF_MAX_DEVICES, PTA_E_ARG, "pta_potrf_batched: device ordinal %d beyond %d", dev, PTA_POTRF_MAX_DEVICES);
+  pta_potrf_ctx &c = g_potrf_ctx[dev];
+  if (!c.ready) {
     for (int i = 0; i < PTA_POTRF_MAX_CHAINS; ++i) {
       PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
       PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
     }
     PTA_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
-    c.dev = dev;
+    c.ready = true;
   }
   *out = &c;
   return PTA_OK;
@@ -437,22 +441,26 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
     // the first panel takes the device: enqueued chain after chain, the second chain starts late - 13 ms under rocprofv3 - and finishes alone; starting chain c only after chain c-1's first panel, so
     // that panel phases meet trailing updates from the start, measured 2 ms SLOWER: the panel kernels are real work, not idle time)
     int k0[PTA_POTRF_MAX_CHAINS] = {0, 0, 0, 0};
-    for (int step = 0, live = nchain; live > 0; ++step) {
+    int rc_chain = PTA_OK;
+    for (int step = 0, live = nchain; live > 0 && rc_chain == PTA_OK; ++step) {
       live = 0;
       for (int c = 0; c < nchain; ++c) {
         if (k0[c] >= n) continue;
         const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
         if (step == 0) PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
-        rc = pta_potrf_step(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, &k0[c],
-                            cx->chain[c]);
-        if (rc != PTA_OK) return rc;
+        rc_chain = pta_potrf_step(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, &k0[c],
+                                  cx->chain[c]);
+        if (rc_chain != PTA_OK) break;
         if (k0[c] < n) ++live;
       }
     }
+    // join on EVERY exit, error included: the caller's stream must not run ahead of (and the caller must not free A under)
+    // chain kernels that are still in flight
     for (int c = 0; c < nchain; ++c) {
-      PTA_HIP(hipEventRecord(cx->ev_out[c], cx->chain[c]));
-      PTA_HIP(hipStreamWaitEvent(s, cx->ev_out[c], 0));  // join: the caller's stream continues after every chain
+      (void)hipEventRecord(cx->ev_out[c], cx->chain[c]);
+      (void)hipStreamWaitEvent(s, cx->ev_out[c], 0);
     }
+    if (rc_chain != PTA_OK) return rc_chain;
   }
   if (flags & PTA_POTRF_ZERO_UPPER) {
     hipLaunchKernelGGL(k_zero_upper, dim3(pta_cdiv(n, 256), n, B), dim3(256), 0, s, A, n, lda, strideA);

@@ -92,7 +92,33 @@ def add_cgw(psr, gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc, pdist=1.0, pph
 
 
 CW_NPAR = 16              # PTA_CW_NPAR
-CW_SCALAR_LOOP_MAX = 20000  # up to this many sources the per-source scalars are evaluated one source at a time (see below)
+
+
+def _dot3(X, y):
+    """row-wise X[i] . y for an [n, 3] array, bit-identical to ``np.dot(X[i], y)`` - the call the reference's loop body makes
+    (deterministic.py:364-372).  np.dot on two 3-vectors is OpenBLAS' ddot, which sums fma(x2 y2, fma(x1 y1, x0 y0)); the native
+    helper pta_dot3_host reproduces that association without a Python-level loop.  Because the association belongs to the BLAS
+    build, it is CHECKED against np.dot on a sample of rows of every call (the first / last 32 and 64 spread between); on a host
+    whose BLAS sums differently the rows are evaluated one np.dot at a time, as before."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n = len(X)
+    out = np.empty(n)
+    _lib.call("pta_dot3_host", dv.hptr(X), n, dv.hptr(y), dv.hptr(out))
+    probe = np.unique(np.concatenate([np.arange(min(n, 32)), np.arange(max(n - 32, 0), n), np.linspace(0, n - 1, 64).astype(np.int64)])) if n else []
+    for i in probe:
+        if out[i] != np.dot(X[i], y) and not (np.isnan(out[i]) and np.isnan(np.dot(X[i], y))):
+            return np.array([np.dot(X[i], y) for i in range(n)])
+    return out
+
+
+def _pow(x, y):
+    """elementwise x ** y through libm's scalar pow (pta_pow_host): what ``np.float64 ** float`` evaluates to in the reference's
+    loop body.  NumPy's array power uses SIMD kernels that differ from libm by an ulp on ~5 % of arguments."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    _lib.call("pta_pow_host", dv.hptr(x), ctypes.c_double(y), x.size, dv.hptr(out))
+    return out
 
 
 def cw_source_params(lists, phat, pdist=1.0, pphase=None):
@@ -100,54 +126,36 @@ def cw_source_params(lists, phat, pdist=1.0, pphase=None):
     them at the top of its numba loops: [ncw, 16] = w0, orbital phase0, w0^(-5/3), fac1, fac2, fac3, incfac1, incfac2, cos 2psi,
     sin 2psi, F+, Fx, pd (1 - cos mu) [s], and for phase_approx omega_p and its phase offset (:395,:399).
 
-    Computed on the HOST with NumPy, like add_cgw's (cgw_parameters): the pulsar-term phase is omega * pd * (1 - cos mu) with
-    pd ~ 1e11 s, so one ulp of cos mu moves a fast binary's phase by up to 4e-11 rad - device sin / cos of the source angles
-    (1-2 ulp) were the largest parity error of the catalogue.  Up to CW_SCALAR_LOOP_MAX sources they are evaluated one source
-    at a time on NumPy float64 SCALARS - the code path the reference's loop body takes, C libm underneath - so they are
-    bit-identical to the reference's; larger catalogues use array expressions (NumPy's SIMD loops can differ from libm by an
-    ulp)."""
+    Computed on the HOST, like add_cgw's (cgw_parameters): the pulsar-term phase is omega * pd * (1 - cos mu) with pd ~ 1e11 s, so
+    one ulp of cos mu moves a fast binary's phase by up to 4e-11 rad - device sin / cos of the source angles (1-2 ulp) were the
+    largest parity error of the catalogue.  ONE code path for every catalogue size (a per-source Python loop up to
+    20 000 sources and array expressions beyond made the results jump by 7e-12 at 20 001 and cost 0.7 s per pulsar below it):
+    the elementwise expressions are NumPy array operations - the same ufunc inner loops a NumPy float64 scalar goes through in the
+    reference's loop body, element for element -, the powers go through libm's scalar pow (_pow) and the three np.dot calls per
+    source, whose association is BLAS', through _dot3.  Bit-identical to the per-source scalar loop (tests/test_host_logic.py)."""
     gwtheta, gwphi, mc, dist, fgw, phase0, psi, inc = lists
     ncw = len(mc)
     par = np.zeros((ncw, CW_NPAR))
-    if ncw <= CW_SCALAR_LOOP_MAX:
-        for i in range(ncw):
-            mci, di = mc[i] * SOLAR2S, dist[i] * MPC2S
-            w0 = np.pi * fgw[i]
-            w053 = w0 ** (-5 / 3)
-            cgt, cgp, sgt, sgp = np.cos(gwtheta[i]), np.cos(gwphi[i]), np.sin(gwtheta[i]), np.sin(gwphi[i])
-            m = np.array([sgp, -cgp, 0.0])
-            nn = np.array([-cgt * cgp, -cgt * sgp, sgt])
-            om = np.array([-sgt * cgp, -sgt * sgp, -cgt])
-            fac1 = 256 / 5 * mci ** (5 / 3) * w0 ** (8 / 3)
-            fac2 = 1 / 32 / mci ** (5 / 3)
-            fac3 = mci ** (5 / 3) / di
-            fplus = 0.5 * (np.dot(m, phat) ** 2 - np.dot(nn, phat) ** 2) / (1 + np.dot(om, phat))
-            fcross = (np.dot(m, phat) * np.dot(nn, phat)) / (1 + np.dot(om, phat))
-            cosMu = -np.dot(om, phat)
-            pd = pphase / (2 * np.pi * fgw[i] * (1 - cosMu)) / KPC2S if pphase is not None else pdist
-            pd = pd * KPC2S
-            omega_p = w0 * (1 + fac1 * pd * (1 - cosMu)) ** (-3 / 8)
-            with np.errstate(all="ignore"):
-                par[i] = (w0, phase0[i] / 2, w053, fac1, fac2, fac3, 0.5 * (3 + np.cos(2 * inc[i])), 2 * np.cos(inc[i]), np.cos(2 * psi[i]),
-                          np.sin(2 * psi[i]), fplus, fcross, pd * (1 - cosMu), omega_p, phase0[i] / 2 + fac2 * (w053 - omega_p ** (-5 / 3)), 0.0)
+    if ncw == 0:
         return par
     with np.errstate(all="ignore"):
         mcs, ds = mc * SOLAR2S, dist * MPC2S
         w0 = np.pi * fgw
-        w053 = w0 ** (-5 / 3)
+        w053 = _pow(w0, -5 / 3)
         cgt, cgp, sgt, sgp = np.cos(gwtheta), np.cos(gwphi), np.sin(gwtheta), np.sin(gwphi)
-        mp = sgp * phat[0] + (-cgp) * phat[1]
-        npd = (-cgt * cgp) * phat[0] + (-cgt * sgp) * phat[1] + sgt * phat[2]
-        op = (-sgt * cgp) * phat[0] + (-sgt * sgp) * phat[1] + (-cgt) * phat[2]
-        fac1 = 256 / 5 * mcs ** (5 / 3) * w0 ** (8 / 3)
-        fac2 = 1 / 32 / mcs ** (5 / 3)
-        fac3 = mcs ** (5 / 3) / ds
+        mp = _dot3(np.stack([sgp, -cgp, np.zeros(ncw)], axis=1), phat)                  # np.dot(m, phat)
+        npd = _dot3(np.stack([-cgt * cgp, -cgt * sgp, sgt], axis=1), phat)              # np.dot(n, phat)
+        op = _dot3(np.stack([-sgt * cgp, -sgt * sgp, -cgt], axis=1), phat)              # np.dot(omhat, phat)
+        mc53 = _pow(mcs, 5 / 3)
+        fac1 = 256 / 5 * mc53 * _pow(w0, 8 / 3)
+        fac2 = 1 / 32 / mc53
+        fac3 = mc53 / ds
         cosMu = -op
         pd = (pphase / (2 * np.pi * fgw * (1 - cosMu)) / KPC2S if pphase is not None else pdist * np.ones(ncw)) * KPC2S
-        omega_p = w0 * (1 + fac1 * pd * (1 - cosMu)) ** (-3 / 8)
+        omega_p = w0 * _pow(1 + fac1 * pd * (1 - cosMu), -3 / 8)
         cols = (w0, phase0 / 2, w053, fac1, fac2, fac3, 0.5 * (3 + np.cos(2 * inc)), 2 * np.cos(inc), np.cos(2 * psi), np.sin(2 * psi),
-                0.5 * (mp ** 2 - npd ** 2) / (1 + op), (mp * npd) / (1 + op), pd * (1 - cosMu), omega_p,
-                phase0 / 2 + fac2 * (w053 - omega_p ** (-5 / 3)), np.zeros(ncw))
+                0.5 * (_pow(mp, 2.0) - _pow(npd, 2.0)) / (1 + op), (mp * npd) / (1 + op), pd * (1 - cosMu), omega_p,
+                phase0 / 2 + fac2 * (w053 - _pow(omega_p, -5 / 3)), np.zeros(ncw))
         for k, c in enumerate(cols):
             par[:, k] = c
     return par

@@ -98,6 +98,9 @@ def generate_gathered(engine, total, r0=0, chunk=256, dst=0, td=False, generate=
     pending = []
     if rank == dst:
         result = torch.empty((total, n_cols), dtype=dtype, device=device)
+        # `result` comes from the caching allocator of the MAIN stream: kernels queued there earlier (a previous call's) may
+        # still be using the block, so the receives - issued from the side stream - start only after them
+        side.after_main()
         for c in range(nchunks):
             lo = c * chunk
             ops = []

@@ -156,6 +156,12 @@ def cholesky_device(A, flags=0):
     batched = A.dim() == 3
     B, n = (A.shape[0], A.shape[1]) if batched else (1, A.shape[0])
     info = dv.zeros((B,), dtype=torch.int32)
+    # P x P ORF factors (a few hundred rows at most): forward-substitution panel solves.  The MFMA product with the inverted
+    # diagonal block brings cond(L11) * eps into the backward error - harmless for the well-conditioned HD matrix, but a
+    # user-supplied anisotropic ORF (clm, lmax > 0) may be close to singular and must still match np.linalg.cholesky at 1e-10
+    # (ADVICE r2); the cost is negligible at this size, the product form stays for the large TD factors
+    if n <= 2048 and not (int(flags) & _lib.POTRF_VALU):
+        flags = int(flags) | _lib.POTRF_SUBSTITUTION
     _lib.call("pta_potrf_batched_ex", dv.ptr(A), n, n, n * n, B, dv.ptr(info), _lib.POTRF_ZERO_UPPER | int(flags), dv.stream_ptr())
     bad = info.cpu().numpy()
     if np.any(bad != 0):

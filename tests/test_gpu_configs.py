@@ -48,16 +48,21 @@ def test_config2_test_partim_set_per_backend_noise_256_realisations():
     assert out.shape == (256, eng.n_toa) and np.all(np.isfinite(out))
     one = _fused_equals_replay(eng, 17)
     assert np.array_equal(one, out[17])
-    # oracle on the dumped draws of one realisation, pulsar 0 (the real tim file)
+    # oracle on the dumped draws of one realisation, EVERY pulsar: the real tim file and the two synthesised ones at their
+    # par-file NTOA (per-backend EFAC / EQUAD / ECORR with 1 s epochs over ~8 sub-band TOAs + per-pulsar RN), 1e-10 relative RMS
     d = eng.dump_draws(3)
-    tf = np.array([f["f"] for f in psrs[0].toas.flags])
-    n = int(eng.counts[0])
-    ref = po.measurement_noise_dt(eng.sigma_s[0], po.flag_vector(tf, z["efac_flags"], z["efac"], n),
-                                  po.flag_vector(tf, z["efac_flags"], 10 ** z["log10_equad"], n), *d["wn"][0])
-    epoch_of, ne, first, _ = po.quantize(eng.mjd[0], tf, dt=1.0 / 86400.0)
-    ref = ref + po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], tf, z["ecorr_flags"]), d["ecorr"][0])
-    ref = ref + po.red_noise_dt(psrs[0].toas.table["tdbld"], float(z["rn_log10_amp"]), float(z["rn_gamma"]), d["rn"][0])
-    assert relrms(out[3, :n], ref) < 1e-10
+    rn_par = [(float(z["rn_log10_amp"]), float(z["rn_gamma"])), (-13.5, 2.5), (-14.2, 4.0)]
+    tf = None
+    for a in range(P):
+        tfa = np.array([f["f"] for f in psrs[a].toas.flags])
+        tf = tfa if a == 0 else tf
+        n = int(eng.counts[a])
+        ref = po.measurement_noise_dt(eng.sigma_s[a], po.flag_vector(tfa, z["efac_flags"], z["efac"], n),
+                                      po.flag_vector(tfa, z["efac_flags"], 10 ** z["log10_equad"], n), *d["wn"][a])
+        epoch_of, ne, first, _ = po.quantize(eng.mjd[a], tfa, dt=1.0 / 86400.0)
+        ref = ref + po.jitter_dt(epoch_of, po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], tfa, z["ecorr_flags"]), d["ecorr"][a])
+        ref = ref + po.red_noise_dt(psrs[a].toas.table["tdbld"], rn_par[a][0], rn_par[a][1], d["rn"][a])
+        assert relrms(out[3, eng.off[a]:eng.off[a + 1]], ref) < 1e-10, a
     # ensemble statistics over 256 realisations: white + ECORR variance of the 430_ASP backend TOAs of pulsar 0
     sel = np.where(tf == "430_ASP")[0]
     k = list(z["efac_flags"]).index("430_ASP")
@@ -93,6 +98,15 @@ def test_config4_headline_array_with_cgw():
         ref = po.cgw_dt(a.mjd[p], np.pi / 2 - dec, ra, **cw)
         assert relrms(det[a.off[p]:a.off[p + 1]], ref) < 2e-10      # evolving phase: see TOL_CGW in tests/test_gpu_parity.py
     _fused_equals_replay(a, 2)
+    # the summed residual (GWB + RN + EFAC/EQUAD + ECORR + CGW) of one realisation against the CPU oracle, EVERY pulsar
+    from helpers import oracle_realisation
+    ref = oracle_realisation(po, psrs, noise, a.dump_draws(1))
+    worst = 0.0
+    for p in range(68):
+        ra, dec = psrs[p].loc["RAJ"] * np.pi / 12, psrs[p].loc["DECJ"] * np.pi / 180
+        full = ref[p] + po.cgw_dt(a.mjd[p], np.pi / 2 - dec, ra, **cw)
+        worst = max(worst, relrms(oa[1, a.off[p]:a.off[p + 1]], full))
+    assert worst < 1e-10, worst
     # one GPU's share of the config (2048 of the 16384 realisations, rank 3's range): batch == one-by-one, finite, and the
     # ensemble variance of one pulsar's residuals is stationary across the shard
     import torch
@@ -150,14 +164,38 @@ def test_config5_ska_scale_anisotropic():
             break
     else:
         pytest.fail("no positive-definite anisotropic ORF found")
+    # the same ORF from the UNMODIFIED reference (oracle/gen_c5_orf.py -> tests/golden/c5_orf_lmax4.npz: all 20 100 pairs through
+    # the reference's own spharmORFbasis functions): geometry, anisotropy coefficients, every degree l, and the sum
+    z = load("c5_orf_lmax4.npz")
+    assert np.array_equal(z["raj"], raj) and np.array_equal(z["decj"], decj) and np.allclose(z["clm"], clm, rtol=0, atol=0)
+    for ll in range(lmax + 1):
+        dev_l = 2 * np.tensordot(clm[ll * ll:(ll + 1) ** 2], basis[ll * ll:(ll + 1) ** 2], axes=1)
+        assert np.max(np.abs(dev_l - z["orf_l"][ll])) < 1e-12 * max(1.0, np.max(np.abs(z["orf_l"][ll]))), ll
+    assert np.max(np.abs(orf - z["orf"])) < 1e-12
     eng = ReplicaEngine(psrs, seed=5)
     eng.set_white_noise(efac=1.0, log10_equad=-6.5)
     eng.set_red_noise(-14.0, 3.0)
     eng.set_gwb(-14.6733, 13. / 3., clm=clm, lmax=lmax)
     eng.prepare()
-    assert np.max(np.abs(eng.ORF.cpu().numpy() - orf)) < 1e-12
+    assert np.max(np.abs(eng.ORF.cpu().numpy() - z["orf"])) < 1e-12
     M = eng.d_M.cpu().numpy()
-    assert np.max(np.abs(M @ M.T - orf)) < 1e-12
+    assert np.max(np.abs(M @ M.T - z["orf"])) < 1e-12
+    Mref = np.linalg.cholesky(z["orf"])                       # LAPACK on the reference's matrix (red_noise.py:235)
+    assert np.max(np.abs(M - Mref)) < 1e-10 * np.max(np.abs(Mref))
     out = eng.generate(2).cpu().numpy()
     assert out.shape == (2, P * N) and np.all(np.isfinite(out))
+    # ---- one whole realisation against the CPU oracle on the dumped deviates, EVERY pulsar: GWB through the reference's ORF and
+    # LAPACK's factor of it (red_noise.py:224-287), RN (:106-135), EFAC / t2EQUAD (white_noise.py:47-125); 1e-10 relative RMS
+    d = eng.dump_draws(1)
+    mjd = [np.asarray(p.toas.get_mjds().value, dtype=np.float64) for p in psrs]
+    grid = po.gwb_grid([float(m.min()) for m in mjd], [float(m.max()) for m in mjd])
+    C = po.gwb_spectrum(grid["f"], grid["dur"], grid["howml"], -14.6733, 13. / 3.)
+    res_gw, _ = po.gwb_dt(grid, Mref, d["gwb"], C, [m * 86400 for m in mjd])
+    worst = 0.0
+    for a in range(P):
+        sig = np.asarray(psrs[a].toas.get_errors().to("s").value, dtype=np.float64)
+        ref = po.measurement_noise_dt(sig, np.ones(N), np.ones(N) * 10 ** -6.5, *d["wn"][a])
+        ref = ref + po.red_noise_dt(psrs[a].toas.table["tdbld"], -14.0, 3.0, d["rn"][a]) + res_gw[a]
+        worst = max(worst, relrms(out[1, eng.off[a]:eng.off[a + 1]], ref))
+    assert worst < 1e-10, worst
     _fused_equals_replay(eng, 1)
