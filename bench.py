@@ -295,6 +295,57 @@ def main():
     elapsed_grid = timed_steps()
     eng.gwb_mode = "fourier"
 
+    # ---- N > 1: what the ranks actually did - an all_reduce of ones over RCCL (ranks seen), every rank's own
+    # ms_per_step (all_gather), and BASELINE.json config 4's shape: 2048 realisations per GPU of the same array + one CGW ----
+    multi = {}
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones)
+        mine = torch.tensor([0.0], dtype=torch.float64, device="cuda")
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            eng.generate(R, r0=base + (W + i) * R, out=out)
+        torch.cuda.synchronize()
+        mine[0] = (time.perf_counter() - t0) / K * 1e3
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        multi = {"rccl_ranks_seen": int(round(float(ones.item()))), "backend": dist.get_backend(),
+                 "ms_per_step_per_rank": [round(float(x.item()), 4) for x in allms]}
+
+    def config4_shape():
+        """BASELINE.json config 4 on this rank: the same 68 x 5000 array + one continuous-wave source (the reference test's CW
+        parameters), 2048 realisations per GPU (16384 over 8), timed like the headline step; returns whole-job realisations/s."""
+        from pta_replicator_amd.distributed import shard_range
+        e4 = configure_engine(type(eng)(psrs, seed=20260921), noise)
+        e4.add_cgw(gwtheta=np.pi / 2, gwphi=2.5, mc=1e9, dist=5.0, fgw=1e-8, phase0=0.5, psi=1.5, inc=np.pi / 4, pdist=1.0, pphase=None,
+                   psrTerm=True, evolve=True, phase_approx=False, tref=53000 * 86400)
+        e4.prepare()
+        per = 2048
+        lo, hi = shard_range(per * world, rank=rank, world=world)
+        buf = dv.empty((per, e4.n_toa))
+        e4.generate(per, r0=lo, out=buf)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            e4.generate(per, r0=lo, out=buf)
+        barrier()
+        el = (time.perf_counter() - t0) / 3
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        del buf
+        return {"realisations_per_gpu": per, "realisations_total": per * world, "ms": el * 1e3, "realisations_per_s": per * world / el,
+                "workload": "BASELINE.json config 4 shape: config 3's array + one CGW (deterministic.py:13-185 parameters of the reference test), "
+                            "realisation ranges by shard_range(); generation only (the gather to rank 0 is `gathered_to_rank0`)"}
+
+    cfg4 = None
+    try:
+        cfg4 = config4_shape()
+    except Exception as e:  # pragma: no cover
+        cfg4 = {"error": str(e)[:300]}
+
     # ---- per-kernel times of one step: HIP events on the stream the kernels are launched on ----
     kern = {}
     s = dv.stream_ptr()
@@ -347,6 +398,7 @@ def main():
             tg = time.perf_counter() - tg
             del full
             res = {"realisations": world * R, "ms": tg * 1e3, "realisations_per_s": world * R / tg,
+                   "gather_ms": tg * 1e3, "generate_only_ms_same_realisations": elapsed / K * 1e3,
                    "note": "every rank generates its shard in chunks of 256 while the previous chunk travels; rank 0 receives straight into the final tensor"}
         except Exception as e:  # pragma: no cover
             res = {"error": str(e)[:300]}
@@ -390,11 +442,21 @@ def main():
         return d
 
     def flop_roof(k):
-        ach = alg_flops_gwb / (kern[k] * 1e-3) / 1e12
+        # the GWB frequency -> time STAGE as the reference writes it is M @ w (4 P^2 Nf flop) + the inverse FFT (5 n log2 n P); on the
+        # device the M @ w term runs in pta_gwb_mix behind the transform (linearity), so the stage's algorithmic flops are divided by
+        # the time of BOTH kernels (dividing by the transform kernel alone flattered it); the transform kernel
+        # alone is quoted against the inverse-FFT flops only, and `executed_tflops` are the flops it actually issues
+        stage_ms = kern[k] + kern["pta_gwb_mix"]
+        ach = alg_flops_gwb / (stage_ms * 1e-3) / 1e12
         bound = "mfma" if k == "pta_gwb_idft_rng" else "valu-fp64"
-        d = {"kernel": k, "bound": bound, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12,
-             "avg_launch_ms": kern[k]}
+        ifft_flops = 5.0 * n_fft * np.log2(n_fft) * P * R
+        d = {"kernel": k, "stage_kernels": [k, "pta_gwb_mix"], "bound": bound, "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+             "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "stage_ms": stage_ms, "avg_launch_ms": kern[k],
+             "transform_kernel_alone": {"algorithmic_ifft_tflops": ifft_flops / (kern[k] * 1e-3) / 1e12,
+                                        "frac": ifft_flops / (kern[k] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                        "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12,
+                                        "executed_frac": exe_flops[k] / (kern[k] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+             "executed_tflops": exe_flops[k] / (kern[k] * 1e-3) / 1e12}
         if k == "pta_gwb_czt":
             e, why = pmc_entry("k_gwb_czt<true, false, 15>", CZT_SRC, rows=R * P)
             if e:
@@ -440,6 +502,18 @@ def main():
         except Exception as e:  # pragma: no cover
             td = {"error": str(e)[:300]}
 
+    # ---- step level (VERDICT r2 #1b): the whole step against the algorithmic flop and deviate counts of SURVEY.md §8d ----
+    n_epochs = int(sum(len(v) for v in eng.ecorrvec)) if getattr(eng, "ecorrvec", None) else 0
+    flops_alg = 4.0 * P * P * Nf + 5.0 * n_fft * np.log2(n_fft) * P + 2.0 * eng.K * eng.n_toa + 10.0 * eng.n_toa
+    deviates = 2.0 * P * Nf + P * eng.K + 2.0 * eng.n_toa + n_epochs
+    step_s = elapsed / K
+    step_block = {"flops_alg_per_realisation": flops_alg, "deviates_per_realisation": deviates,
+                  "achieved_TFLOPs": flops_alg * R / step_s / 1e12, "frac_of_fp64_peak": flops_alg * R / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                  "normals_T_per_s": deviates * R / step_s / 1e12,
+                  "frac_of_rng_microbench": (deviates * R / step_s / 1e12 / micro["normals_T_per_s"]) if micro.get("normals_T_per_s") else None,
+                  "sum_kernels_ms": sum(kern[k] for k in ("pta_engine_rn_coef", gwb_kernel, "pta_gwb_mix", "pta_engine_synth")),
+                  "note": "flops = 4 P^2 Nf + 5 n log2 n P + 2 K sum N_a + 10 sum N_a; deviates = 2 P Nf + P K + 2 sum N_a + sum E_a (SURVEY.md §8d)"}
+
     line = {
         "metric": "realizations/sec, 68 psr x 5000 TOAs GWB+RN+WN", "value": world * R * K / elapsed, "unit": "realizations/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -450,10 +524,14 @@ def main():
                    "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
         "value_fast_rng_math": world * R * K / elapsed_fast,
         "value_gwb_grid_draws": world * R * K / elapsed_grid,
-        "roofline": roof, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
+        "roofline": roof, "step": step_block, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
     }
+    if world > 1:
+        line.update(multi)
     if td is not None:
         line["td_mode"] = td
+    if cfg4 is not None:
+        line["config4_shape"] = cfg4
     if world > 1 and not args.no_gather:
         gather_phase(line)
     if world == 1 and not args.no_cpu_baseline:
@@ -461,6 +539,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(psrs, noise)
             line["gpu_over_cpu"] = {"with_reference_dense_U_ecorr": line["value"] / line["cpu_baseline"]["value"],
                                     "without_ecorr": line["value"] / line["cpu_baseline"]["value_without_ecorr"]}
+            # the UNMODIFIED reference timed in the build container (the only place /root/reference exists): a committed record,
+            # not measured in this run - on the GPU box the live figure above is the NumPy port (kind "port")
+            ref_rec = os.path.join(ROOT, "profiles", "r03_cpu_baseline_reference.json")
+            if os.path.exists(ref_rec):
+                with open(ref_rec) as fh:
+                    rc_ = json.load(fh)
+                line["cpu_baseline"]["reference_container"] = rc_
+                line["gpu_over_cpu"]["vs_reference_container_with_dense_U_ecorr"] = line["value"] / rc_["value"]
+                line["gpu_over_cpu"]["vs_reference_container_without_ecorr"] = line["value"] / rc_["value_without_ecorr"]
         except Exception as e:  # pragma: no cover
             line["cpu_baseline"] = {"error": str(e)[:400]}
     print(json.dumps(line))

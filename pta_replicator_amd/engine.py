@@ -607,24 +607,43 @@ class ReplicaEngine(TimeDomainMixin):
             psr.update_residuals()
         return row
 
-    def to_enterprise(self, rows, subtract_mean=True):
+    def to_enterprise(self, rows, subtract_mean=True, timing_model="spin"):
         """enterprise-style pulsar objects for realisations already generated: ``rows`` is a [R, n_toa] tensor / array (e.g. the
-        output of generate() or generate_td()); returns R lists of P ``ArrayEnterprisePulsar`` whose ``residuals`` are the injected
-        delays with the weighted mean removed (what PINT's Residuals would report for an idealised pulsar) -
-        the hand-off of SURVEY.md §8f rank 4 for whole ensembles, without a par/tim round trip."""
+        output of generate() or generate_td()); returns R lists of P ``ArrayEnterprisePulsar`` whose ``toas`` are the ideal TOAs
+        shifted by the realisation's delay (what the reference's hand-off carries, simulate.py:91-95) and whose ``residuals`` are the
+        injected delays with the weighted mean removed (what PINT's Residuals would report for an idealised pulsar, SURVEY.md §8
+        a16) - the hand-off of SURVEY.md §8f rank 4 for whole ensembles, without a par/tim round trip.  Works for array-backed,
+        PINT-backed and foreign pulsars alike: everything is read from the engine's own copies of the ideal TOAs / errors and the
+        pulsar's flag table."""
         from .simulate import ArrayEnterprisePulsar
+        from ._position import ra_dec
         arr = rows.detach().cpu().numpy() if hasattr(rows, "detach") else np.asarray(rows)
         if arr.ndim == 1:
             arr = arr[None, :]
+        meta = []
+        for a, psr in enumerate(self.psrs):
+            toas = psr.toas
+            flags = list(toas.table["flags"].data)
+            freq = getattr(toas, "freqs_mhz", None)
+            if freq is None:
+                try:
+                    freq = np.asarray(toas.get_freqs().to("MHz").value, dtype=np.float64)
+                except AttributeError:
+                    freq = 1440.0
+            meta.append((flags, np.asarray(freq, dtype=np.float64) * np.ones(int(self.counts[a])), ra_dec(psr, default=(0.0, 0.0))))
         out = []
         for row in arr:
             psrs = []
             for a, psr in enumerate(self.psrs):
                 x = row[self.off[a]:self.off[a + 1]]
+                res = x
                 if subtract_mean:
-                    w = 1.0 / np.asarray(psr.toas.get_errors().to("us").value, dtype=np.float64) ** 2
-                    x = x - np.sum(x * w) / np.sum(w)
-                psrs.append(ArrayEnterprisePulsar.from_simulated(psr, residuals_s=x))
+                    w = 1.0 / self.sigma_s[a] ** 2
+                    res = x - np.sum(x * w) / np.sum(w)
+                flags, freq, (ra, dec) = meta[a]
+                mjd = self.mjd[a].astype(np.longdouble) + (x / 86400.0).astype(np.longdouble)
+                psrs.append(ArrayEnterprisePulsar(psr.name, np.asarray(mjd, dtype=np.float64), res, self.sigma_s[a] * 1e6, freq, flags, ra, dec,
+                                                  timing_model=timing_model))
             out.append(psrs)
         return out
 

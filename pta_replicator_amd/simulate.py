@@ -182,18 +182,43 @@ class SimulatedPulsar:
         return Pulsar(self.toas, self.model, ephem=ephem, timing_package="pint")
 
 
+def timing_design_matrix(toas_s, ra=0.0, dec=0.0, model="spin"):
+    """Design matrix of an idealised isolated pulsar's timing model on the TOAs ``toas_s`` [s]: the columns a
+    timing fit would project out of the injected delays.  ``model``:
+      "spin"         offset, F0 (t), F1 (t^2)                                                                    3 columns
+      "astrometric"  + position (annual cos / sin), proper motion (t x annual cos / sin), parallax (semi-annual)  9 columns
+    Columns are scaled to unit maximum (what enterprise's TimingModel does with ``normed=True``); the projection
+    r - M (M^T W M)^-1 M^T W r is invariant under column scaling.  This is NOT PINT's design matrix of the pulsar's par file (binary,
+    DM and JUMP columns are absent - PINT is not installable here, f4 is unpinned); it spans the same subspace for an isolated pulsar
+    with a quadratic spin-down and linearised astrometry."""
+    t = np.asarray(toas_s, dtype=np.float64)
+    t = t - t.mean()
+    scale = max(float(np.max(np.abs(t))), 1.0)
+    x = t / scale
+    cols, names = [np.ones_like(x), x, x ** 2], ["Offset", "F0", "F1"]
+    if model == "astrometric":
+        w = 2.0 * np.pi / (365.25 * 86400.0)
+        c, s = np.cos(w * t), np.sin(w * t)
+        cols += [c, s, x * c, x * s, np.cos(2 * w * t), np.sin(2 * w * t)]
+        names += ["RAJ", "DECJ", "PMRA", "PMDEC", "PX", "PX_quad"]
+    elif model != "spin":
+        raise ValueError(f"{model=} must be 'spin' or 'astrometric'")
+    return np.stack(cols, axis=1), names
+
+
 class ArrayEnterprisePulsar:
     """The part of ``enterprise.pulsar.BasePulsar`` that enterprise's signal classes read, filled straight from arrays
     (lets an analysis consume GPU-generated realisations without writing and re-reading par/tim files).
 
     Attributes, in enterprise's units: ``name``; ``toas`` [s, MJD * 86400]; ``residuals`` [s]; ``toaerrs`` [s]; ``freqs`` [MHz];
     ``flags`` (dict flag -> array of str, one entry per TOA, '' where a TOA lacks the flag); ``backend_flags`` (the 'f' flag, else
-    'group'/'be' as enterprise falls back); ``Mmat`` [N x 3] timing-model design matrix of an idealised pulsar (offset, t, t^2 -
-    the columns that absorb the mean and the spin-down a fit would remove); ``pos`` unit vector, ``theta`` / ``phi`` [rad];
-    ``pdist`` (1.0, 0.2) kpc as enterprise defaults it.  UNPINNED: enterprise is not installed here and the reference has no
-    test of its hand-off; the attribute list follows enterprise/pulsar.py."""
+    'group'/'be' as enterprise falls back); ``Mmat`` the timing-model design matrix of an idealised pulsar (timing_design_matrix:
+    "spin" = offset, t, t^2 - the columns that absorb the mean and the spin-down a fit would remove -, or "astrometric" = 9
+    columns); ``pos`` unit vector, ``theta`` / ``phi`` [rad]; ``pdist`` (1.0, 0.2) kpc as enterprise defaults it.  UNPINNED:
+    enterprise is not installed here and the reference has no test of its hand-off; the attribute list follows
+    enterprise/pulsar.py."""
 
-    def __init__(self, name, mjd, residuals_s, toaerrs_us, freqs_mhz, flags, ra, dec):
+    def __init__(self, name, mjd, residuals_s, toaerrs_us, freqs_mhz, flags, ra, dec, timing_model="spin"):
         order = np.argsort(np.asarray(mjd, dtype=np.float64), kind="mergesort")   # enterprise sorts TOAs by default (sort=True)
         self.name = name
         self._isort = order
@@ -210,21 +235,42 @@ class ArrayEnterprisePulsar:
                 break
         else:
             self.backend_flags = np.array([""] * len(order))
-        t = self.toas - self.toas.mean()
-        scale = max(float(np.max(np.abs(t))), 1.0)
-        self.Mmat = np.stack([np.ones_like(t), t / scale, (t / scale) ** 2], axis=1)
-        self.fitpars = ["Offset", "F0", "F1"]
+        self.Mmat, self.fitpars = timing_design_matrix(self.toas, ra, dec, timing_model)
         self.theta, self.phi = float(np.pi / 2 - dec), float(ra)
         self.pos = np.array([np.cos(ra) * np.cos(dec), np.sin(ra) * np.cos(dec), np.sin(dec)])
         self.pdist = (1.0, 0.2)
         self.dm = None
 
     @classmethod
-    def from_simulated(cls, psr, residuals_s=None):
+    def from_simulated(cls, psr, residuals_s=None, toa_shift_s=None, timing_model="spin"):
+        """From any pulsar object with the duck-type surface of SURVEY.md §8b (array-backed, PINT-backed or foreign): TOAs, errors and
+        flags are read through get_mjds() / get_errors() / table['flags'], the way the injection functions read them.  The TOAs
+        handed over are the CURRENT (shifted) ones, like the reference's hand-off (simulate.py:91-95 passes the adjusted TOAs);
+        ``toa_shift_s`` adds a further per-TOA shift [s] (ReplicaEngine.to_enterprise: ideal TOAs + the realisation's delay)."""
         from ._position import ra_dec
         ra, dec = ra_dec(psr, default=(0.0, 0.0))
-        res = psr.residuals.resids_value if residuals_s is None else residuals_s
-        return cls(psr.name, psr.toas.mjd0_ld.astype(np.float64), res, psr.toas.errors_us, psr.toas.freqs_mhz, psr.toas.flags, ra, dec)
+        toas = psr.toas
+        if isinstance(toas, ArrayTOAs):
+            mjd, err, freq, flags = toas.mjd_ld, toas.errors_us, toas.freqs_mhz, toas.flags
+        else:
+            mjd = np.asarray(toas.get_mjds().value, dtype=np.longdouble)
+            err = np.asarray(toas.get_errors().to("us").value, dtype=np.float64)
+            flags = list(toas.table["flags"].data)
+            try:
+                freq = np.asarray(toas.get_freqs().to("MHz").value, dtype=np.float64)
+            except AttributeError:
+                freq = np.asarray(getattr(toas, "freqs_mhz", 1440.0), dtype=np.float64) * np.ones(len(mjd))
+        if toa_shift_s is not None:
+            mjd = np.asarray(mjd, dtype=np.longdouble) + (np.asarray(toa_shift_s, dtype=np.float64) / 86400.0).astype(np.longdouble)
+        if residuals_s is None:
+            if psr.residuals is None:
+                psr.update_residuals()
+            res = getattr(psr.residuals, "resids_value", None)
+            if res is None:
+                res = np.asarray(psr.residuals.time_resids.to("s").value, dtype=np.float64)
+        else:
+            res = residuals_s
+        return cls(psr.name, np.asarray(mjd, dtype=np.float64), res, err, freq, flags, ra, dec, timing_model=timing_model)
 
     def __repr__(self):
         return f"ArrayEnterprisePulsar({self.name}, {len(self.toas)} TOAs)"

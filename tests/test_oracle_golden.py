@@ -310,3 +310,18 @@ def test_red_noise_explicit_modes():
             (zr,) = po.legacy_normals(4242 + i, [2 * len(z["modes"])])
             dt = po.red_noise_dt(mjd_ld(z, "", i), -13.3, 3.7, zr, components=30, libstempo_convention=conv, modes=z["modes"])
             assert relrms(dt, z["rn_" + tag][i]) < TOL, (tag, i)
+
+
+def test_config5_orf_fixture_pins_the_oracle_basis_at_lmax4():
+    """tests/golden/c5_orf_lmax4.npz (oracle/gen_c5_orf.py: all 20 100 pairs of BASELINE.json config 5 through the UNMODIFIED
+    reference's spharmORFbasis functions) against the NumPy restatement on its leading 14 x 14 block, degree by degree."""
+    z = load("c5_orf_lmax4.npz")
+    n, lmax = 14, int(z["lmax"])
+    locs = po.psr_locs_equatorial([{"RAJ": z["raj"][a], "DECJ": z["decj"][a]} for a in range(n)])
+    basis = np.array(po.correlated_basis(locs, lmax))
+    clm = z["clm"]
+    for ll in range(lmax + 1):
+        got = 2 * np.tensordot(clm[ll * ll:(ll + 1) ** 2], basis[ll * ll:(ll + 1) ** 2], axes=1)
+        assert np.max(np.abs(got - z["orf_l"][ll][:n, :n])) < 1e-13 * max(1.0, float(np.max(np.abs(z["orf_l"][ll])))), ll
+    assert np.max(np.abs(po.gwb_orf(locs, clm, lmax) - z["orf"][:n, :n])) < 1e-13
+    assert np.all(np.linalg.eigvalsh(z["orf"]) > 0.5) and z["orf"].shape == (200, 200)
