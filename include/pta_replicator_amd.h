@@ -150,6 +150,8 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 #define PTA_POTRF_SUBSTITUTION 4  /* panel solves by forward substitution instead of the MFMA product with the inverted diagonal
                                      block: LAPACK-grade backward error also when the diagonal blocks are very ill-conditioned
                                      (cond(L11) * eps enters the product form) - used for the GWB grid covariance, cond ~ 3e14 */
+#define PTA_POTRF_GLDS 32         /* trailing / panel-internal updates on 128 x 128 tiles with the operand slabs staged by LDS DMA
+                                     (global_load_lds_dwordx4, pta_dgemm algo 2) instead of through registers */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 
@@ -377,7 +379,8 @@ int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, in
 /* C[b] = alpha * A[b] * op(B[b]) + beta * C[b], row-major, batch `batch` with element strides.
  * A element (m,k) = A[m*lda + k*ska] (ska = 2 reads the real or imaginary plane of interleaved
  * complex rows); transB = 0: B is [K x N]; 1: B is [N x K].  lower_only = 1 touches only col <= row
- * (SYRK).  algo 0 = VALU reference kernel, 1 = v_mfma_f64_16x16x4_f64 kernel.                */
+ * (SYRK).  algo 0 = VALU reference kernel, 1 = v_mfma_f64_16x16x4_f64 kernel, 2 = the MFMA kernel whose 128 x 128-tile form stages
+ * its operand slabs by LDS DMA (transB = 1, ska = 1, even K / lda / ldb / strides, 16-byte aligned A and B; else as algo 1). */
 int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
               const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
               int64_t strideA, int64_t strideB, int64_t strideC, int algo, void *stream);

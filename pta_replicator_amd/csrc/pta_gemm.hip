@@ -297,6 +297,169 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
   }
 }
 
+// ---- direct-to-LDS variant (algo 2) ------------------------------------------------------------------------------------
+// Same 128 x 128 tile, same wave layout and epilogue as k_dgemm_mfma128<true, true>, but the operand slabs never pass through
+// registers: every wave issues global_load_lds_dwordx4 (16 bytes per lane straight into LDS; destination = wave-uniform base +
+// lane * 16) for the NEXT slab at the top of an iteration and the data is only waited for at that iteration's closing barrier,
+// 64 MFMAs later.  That removes from the K loop the 16 staging VGPRs x 2, the s_waitcnt vmcnt(0) in front of 16 ds_write_b64
+// per thread, the writes themselves (ds_write_b64 sustains a third of the read rate) and, with the k-permutation below, half of
+// the fragment reads:
+//   * LDS image of a slab: row-major, 128 rows x 16 k = 128 bytes per row, no padding (the DMA writes lane-linearly), 16-byte
+//     chunk c of row r stored at slot c ^ f(r), f(r) = (e & 1) | 6 * ((e >> 2) & 1), e = (r >> 1) & 7.  The swizzle is applied on
+//     the SOURCE side (each lane fetches the chunk that belongs in the slot it writes) and again on the fragment reads, where it
+//     makes every ds_read_b128 conflict-free: the instruction is serviced in the four lane groups {0-3, 12-15, 20-27}, {4-11,
+//     16-19, 28-31}, +32 (MI355X_MICROARCH.md, LDS), each of which holds the 16 rows of a fragment once, eight of them reading
+//     chunk c and eight chunk c ^ 2 - f() sends those two sets to complementary slots of the 256-byte bank row.
+//   * the sum over k is order independent, so MFMA step t of a slab gives k-slot q = lane >> 4 the column k = 4 q + t (not
+//     4 t + q): a lane's four A (or B) values of a slab are 32 contiguous bytes of its row = two ds_read_b128 instead of four
+//     ds_read_b64, 16 per wave and slab in all, issued as two waves of eight so that the first 32 MFMAs start while the second
+//     half is still landing.
+// Rows past M / N and k past K are fetched from clamped (valid) addresses; a K tail (K % 16 != 0) zeroes the fragments of the
+// slots past K in registers, in the last iteration only.  Requirements as for VEC: transB, unit k stride, even K and leading
+// dimensions, 16-byte aligned operands.
+#define GL_ROWB 128                       // bytes per LDS row (16 doubles)
+#define GL_OPB (HBM_T * GL_ROWB)          // bytes per operand slab: 16 KB
+__device__ __forceinline__ int pta_gl_f(int row) {
+  const int e = (row >> 1) & 7;
+  return (e & 1) | (((e >> 2) & 1) * 6);
+}
+
+__global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, double alpha, const double *__restrict__ A, int64_t lda,
+                                                          const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C,
+                                                          int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC) {
+  int bm = blockIdx.y, bn = blockIdx.x;
+  if (lower_only == 2) {
+    const int tix = blockIdx.x;
+    bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+    while (bm * (bm + 1) / 2 > tix) --bm;
+    bn = tix - bm * (bm + 1) / 2;
+  } else if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) {
+    return;
+  }
+  A += (int64_t)blockIdx.z * sA;
+  B += (int64_t)blockIdx.z * sB;
+  C += (int64_t)blockIdx.z * sC;
+  __shared__ double __attribute__((aligned(256))) slab[2][2][HBM_T * GBK];  // [stage][operand][row * 16 + k], swizzled per row
+  const int t = threadIdx.x, l = t & 63, w = t >> 6;
+  const int wm = w >> 1, wn = w & 1;
+  const int m0 = bm * HBM_T, n0 = bn * HBM_T;
+  typedef double pta_f64x2 __attribute__((ext_vector_type(2)));
+  // ---- DMA side: wave w stages rows [32 w, 32 w + 32) of both operands, 8 rows per instruction
+  const double *__restrict__ srcA[4];
+  const double *__restrict__ srcB[4];
+  int kc[4];  // first k (inside a slab) of the chunk this lane fetches in instruction j
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 32 * w + 8 * j + (l >> 3);
+    kc[j] = 2 * ((l & 7) ^ pta_gl_f(row));
+    srcA[j] = A + (int64_t)min(m0 + row, M - 1) * lda;
+    srcB[j] = B + (int64_t)min(n0 + row, N - 1) * ldb;
+  }
+  auto stage = [&](int k0, int st) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = min(k0 + kc[j], K - 2);
+      char *dA = reinterpret_cast<char *>(&slab[st][0][0]) + (32 * w + 8 * j) * GL_ROWB;
+      char *dB = reinterpret_cast<char *>(&slab[st][1][0]) + (32 * w + 8 * j) * GL_ROWB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[j] + k),
+                                       (__attribute__((address_space(3))) void *)dA, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcB[j] + k),
+                                       (__attribute__((address_space(3))) void *)dB, 16, 0, 0);
+    }
+  };
+  // ---- fragment side: lane (i = l & 15, q = l >> 4) reads chunks 2 q and 2 q + 1 of rows 16 blk + i
+  const int fi = l & 15, fq = l >> 4;
+  const int fsw = pta_gl_f(fi);  // rows 16 blk + i share (row >> 1) & 7 with i
+  const int offA = (wm * 64 + fi) * GL_ROWB, offB = (wn * 64 + fi) * GL_ROWB;
+  const int c0 = ((2 * fq) ^ fsw) * 16, c1 = ((2 * fq + 1) ^ fsw) * 16;
+  pta_f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+  // one slab: 16 fragment reads (the eight that feed MFMA steps 0 / 1 first), then 64 MFMAs.  `kv` < 16 only for a K tail, which runs
+  // as a peeled last iteration so that the steady-state loop carries no selects and its waits stay progressive.
+  auto slab_product = [&](int cur, int kv, int next_k0) {
+    const char *pa = reinterpret_cast<const char *>(&slab[cur][0][0]) + offA;
+    const char *pb = reinterpret_cast<const char *>(&slab[cur][1][0]) + offB;
+    pta_f64x2 a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a0[i] = *reinterpret_cast<const pta_f64x2 *>(pa + i * 16 * GL_ROWB + c0);
+      b0[i] = *reinterpret_cast<const pta_f64x2 *>(pb + i * 16 * GL_ROWB + c0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a1[i] = *reinterpret_cast<const pta_f64x2 *>(pa + i * 16 * GL_ROWB + c1);
+      b1[i] = *reinterpret_cast<const pta_f64x2 *>(pb + i * 16 * GL_ROWB + c1);
+    }
+    if (kv < GBK) {  // K tail: slots past K contribute nothing (their loads were clamped duplicates, possibly NaN scratch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (4 * fq + 0 >= kv) a0[i].x = 0.0, b0[i].x = 0.0;
+        if (4 * fq + 1 >= kv) a0[i].y = 0.0, b0[i].y = 0.0;
+        if (4 * fq + 2 >= kv) a1[i].x = 0.0, b1[i].x = 0.0;
+        if (4 * fq + 3 >= kv) a1[i].y = 0.0, b1[i].y = 0.0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a0[i].x, b0[j].x, acc[i][j]);
+    // the next slab's DMA is issued HERE, behind the fragment reads and the first 16 MFMAs: a DMA piece costs ~60 issue cycles
+    // (MI355X_MICROARCH.md), which then pass while the matrix pipe works through the queue instead of in front of the reads; its
+    // buffer (cur ^ 1) was last read before the previous barrier
+    if (next_k0 >= 0) stage(next_k0, cur ^ 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a0[i].y, b0[j].y, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a1[i].x, b1[j].x, acc[i][j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a1[i].y, b1[j].y, acc[i][j]);
+    // the closing barrier carries s_waitcnt vmcnt(0) for the DMA issued at the top of the iteration: it must stay BEHIND the 64
+    // MFMAs (left alone, the scheduler hoists it to right after the first one - the product only touches registers - and the DMA
+    // latency is then waited for, every slab, instead of hiding under 4096 matrix-pipe cycles)
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const int nfull = K / GBK, ktail = K - nfull * GBK, nslab = nfull + (ktail ? 1 : 0);
+  stage(0, 0);
+  __syncthreads();  // drains the DMA (vmcnt(0)) before any wave reads the slab
+  for (int sidx = 0; sidx < nfull; ++sidx) {
+    slab_product(sidx & 1, GBK, sidx + 1 < nslab ? (sidx + 1) * GBK : -1);
+    __syncthreads();  // every wave is done reading this slab; the DMA of the next one has landed
+  }
+  if (ktail) slab_product(nfull & 1, ktail, -1);
+  const int colb = n0 + wn * 64 + pta_mfma_col(l);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rowb = m0 + wm * 64 + i * 16 + (l >> 4);
+    double cv[4][4];
+    if (beta != 0.0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cv[j][r] = C[(int64_t)min(rowb + 4 * r, M - 1) * ldc + min(colb + j * 16, N - 1)];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rowb + 4 * r, col = colb + j * 16;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v = fma(beta, cv[j][r], v);
+        if (row < M && col < N && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
+      }
+  }
+}
+
 // plain VALU kernel: one thread per C element.  Cross-check for the MFMA kernel and the fallback
 // for operand shapes too small to fill a tile.
 template <bool BT>
@@ -331,7 +494,7 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
       hipLaunchKernelGGL(k_dgemm_valu<true>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else
       hipLaunchKernelGGL(k_dgemm_valu<false>, g, dim3(128), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
-  } else if (algo == 1 && M >= 256 && N >= 128 && K >= 32) {  // large operands: 128x128 tiles
+  } else if (algo >= 1 && M >= 256 && N >= 128 && K >= 32) {  // large operands: 128x128 tiles (algo 2: operand slabs by LDS DMA)
     PTA_REQUIRE(pta_cdiv(M, HBM_T) <= 65535u, PTA_E_ARG, "pta_dgemm: M=%d too large", M);
     dim3 g(pta_cdiv(N, HBM_T), pta_cdiv(M, HBM_T), batch);
     if (lower_only && M == N) {
@@ -341,7 +504,9 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
     }
     const bool vec = transB && ska == 1 && (K % 2) == 0 && (lda % 2) == 0 && (ldb % 2) == 0 && (sA % 2) == 0 && (sB % 2) == 0 &&
                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
-    if (vec)
+    if (vec && algo == 2)
+      hipLaunchKernelGGL(k_dgemm_glds128, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+    else if (vec)
       hipLaunchKernelGGL((k_dgemm_mfma128<true, true>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else if (transB)
       hipLaunchKernelGGL((k_dgemm_mfma128<true, false>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);

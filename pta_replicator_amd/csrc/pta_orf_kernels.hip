@@ -418,7 +418,9 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
   PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
               (long long)lda, (long long)strideA);
   hipStream_t s = pta_stream(stream);
-  const int algo = (flags & PTA_POTRF_VALU) ? 0 : 1;  // 0: VALU reference GEMM + substitution panel solve (cross-check)
+  // 0: VALU reference GEMM + substitution panel solve (cross-check); 1: MFMA kernels, register-staged operand slabs; 2: the same with
+  // the 128 x 128-tile products' operand slabs brought in by LDS DMA (k_dgemm_glds128)
+  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_GLDS) ? 2 : 1);
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default

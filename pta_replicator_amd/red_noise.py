@@ -149,10 +149,11 @@ def gwb_orf_device(psrs, no_correlations=False, clm=(np.sqrt(4.0 * np.pi),), lma
     return anis.orf_from_locations(psrlocs, clm, lmax)
 
 
-def cholesky_device(A, flags=0):
+def cholesky_device(A, flags=0, auto_substitution=True):
     """lower Cholesky factor of a [n,n] (or [B,n,n]) device tensor, in place; raises numpy's LinAlgError
     like np.linalg.cholesky (red_noise.py:235) when a matrix is not positive definite.  `flags`: extra PTA_POTRF_* bits
-    (e.g. _lib.POTRF_VALU for the all-VALU cross-check path)."""
+    (e.g. _lib.POTRF_VALU for the all-VALU cross-check path).  `auto_substitution=False` leaves the choice of the panel solve to
+    `flags` alone (tests of the MFMA product form)."""
     batched = A.dim() == 3
     B, n = (A.shape[0], A.shape[1]) if batched else (1, A.shape[0])
     info = dv.zeros((B,), dtype=torch.int32)
@@ -160,7 +161,7 @@ def cholesky_device(A, flags=0):
     # diagonal block brings cond(L11) * eps into the backward error - harmless for the well-conditioned HD matrix, but a
     # user-supplied anisotropic ORF (clm, lmax > 0) may be close to singular and must still match np.linalg.cholesky at 1e-10
     # (ADVICE r2); the cost is negligible at this size, the product form stays for the large TD factors
-    if n <= 2048 and not (int(flags) & _lib.POTRF_VALU):
+    if auto_substitution and n <= 2048 and not (int(flags) & _lib.POTRF_VALU):
         flags = int(flags) | _lib.POTRF_SUBSTITUTION
     _lib.call("pta_potrf_batched_ex", dv.ptr(A), n, n, n * n, B, dv.ptr(info), _lib.POTRF_ZERO_UPPER | int(flags), dv.stream_ptr())
     bad = info.cpu().numpy()

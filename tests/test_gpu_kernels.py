@@ -115,6 +115,35 @@ def test_dgemm_mfma_and_valu(gpu, shape, transB):
         assert np.max(np.abs(Cd.cpu().numpy() - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (algo, shape)
 
 
+@pytest.mark.parametrize("shape", [(256, 128, 32), (300, 257, 76), (515, 400, 64), (1000, 520, 1032), (640, 640, 250)])
+@pytest.mark.parametrize("lower", [0, 1])
+def test_dgemm_lds_dma_operand_staging(gpu, shape, lower):
+    """pta_dgemm algo 2 (k_dgemm_glds128: operand slabs by global_load_lds, swizzled LDS image, permuted k slots) against NumPy and
+    against algo 1, on operands that are SUB-BLOCKS of wider arrays whose other columns hold NaN - a K tail (K % 16 != 0) must not
+    pick up what lies behind column K, rows past M / N are clamped duplicates that are never stored; batch of 2, square lower_only."""
+    dv, lib = gpu["dv"], gpu["lib"]
+    M, N, K = shape
+    if lower:
+        N = M
+    rng = np.random.default_rng(M + 7 * N + 13 * K)
+    lda, ldb, Bt = K + 22, K + 6, 2
+    A = np.full((Bt, M, lda), np.nan); Bm = np.full((Bt, N, ldb), np.nan)
+    A[:, :, 4:4 + K] = rng.standard_normal((Bt, M, K)); Bm[:, :, 2:2 + K] = rng.standard_normal((Bt, N, K))
+    C0 = rng.standard_normal((Bt, M, N))
+    ref = 0.7 * A[:, :, 4:4 + K] @ Bm[:, :, 2:2 + K].transpose(0, 2, 1) - 1.3 * C0
+    got = {}
+    for algo in (1, 2):
+        Ad, Bd, Cd = dv.f64(A), dv.f64(Bm), dv.f64(C0)
+        lib.call("pta_dgemm", 1, M, N, K, 0.7, ctypes.c_void_p(Ad.data_ptr() + 8 * 4), lda, 1, ctypes.c_void_p(Bd.data_ptr() + 8 * 2), ldb, -1.3,
+                 dv.ptr(Cd), N, lower, Bt, M * lda, N * ldb, M * N, algo, gpu["s"])
+        got[algo] = Cd.cpu().numpy()
+        sel = np.tril(np.ones((M, N), bool)) if lower else np.ones((M, N), bool)
+        assert np.all(np.isfinite(got[algo]))
+        assert np.max(np.abs(got[algo][:, sel] - ref[:, sel])) < 1e-11 * max(1.0, np.max(np.abs(ref))), (algo, shape)
+        if lower:
+            assert np.array_equal(got[algo][:, ~sel], C0[:, ~sel])
+
+
 def test_dgemm_batched_strided_lower(gpu):
     """batch + element stride on A (planes of interleaved complex) + SYRK-style lower_only."""
     dv, lib = gpu["dv"], gpu["lib"]
@@ -163,10 +192,11 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
     rng = np.random.default_rng(n)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
-    # VALU cross-check, default (MFMA), substitution solves, one chain, and 256-wide panels on 3 / 4 chains
+    # VALU cross-check, default (MFMA product solves), substitution solves, one chain, 256-wide panels on 3 / 4 chains, and the
+    # LDS-DMA operand staging of the 128-tile updates
     for flags in (lib.POTRF_VALU, 0, lib.POTRF_SUBSTITUTION, lib.POTRF_NO_LOOKAHEAD,
-                  lib.POTRF_CHAINS(3) | lib.POTRF_NB(1), lib.POTRF_CHAINS(4) | lib.POTRF_NB(1)):
-        L = rn.cholesky_device(dv.f64(A), flags).cpu().numpy()
+                  lib.POTRF_CHAINS(3) | lib.POTRF_NB(1), lib.POTRF_CHAINS(4) | lib.POTRF_NB(1), lib.POTRF_GLDS, lib.POTRF_GLDS | lib.POTRF_NB(1)):
+        L = rn.cholesky_device(dv.f64(A), flags, auto_substitution=False).cpu().numpy()
         ref = np.linalg.cholesky(A)
         assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, flags)
         assert np.all(np.triu(L, 1) == 0)
