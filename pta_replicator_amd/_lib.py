@@ -78,6 +78,8 @@ _SIGNATURES = {
     "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_potrf_batched": (c_int, [_P, c_int, c_int, _P, _P]),
     "pta_potrf_batched_ex": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P]),
+    "pta_potrf_workspace_doubles": (c_int64, [c_int, c_int, c_int]),
+    "pta_potrf_batched_ws": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P, c_int64, _P]),
     "pta_gwb_twiddle": (c_int, [_P, c_int, c_int, c_int, c_double, _P, c_int64, _P]),
     "pta_gwb_idft": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_gwb_twiddle_sym_size": (c_int64, [c_int, c_int, c_int, POINTER(c_int64)]),
@@ -109,7 +111,7 @@ _SIGNATURES = {
 ENGINE_TILE = 256   # PTA_ENGINE_TILE
 ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
 TD_STRIP = 256      # PTA_TD_STRIP
-POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION, POTRF_VALU, POTRF_GLDS = 1, 2, 4, 8, 32
+POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION, POTRF_VALU, POTRF_REG_STAGING, POTRF_LOCKSTEP = 1, 2, 4, 8, 32, 64
 
 
 def POTRF_CHAINS(c):

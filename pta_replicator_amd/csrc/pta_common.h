@@ -41,3 +41,4 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int algo, hipStream_t stream);
 
+int pta_dgemm_tile_n(int M, int N, int K, int algo);

@@ -482,6 +482,10 @@ __global__ void k_dgemm_valu(int M, int N, int K, double alpha, const double *__
   C[o] = (beta == 0.0) ? v : v + beta * C[o];
 }
 
+// width of the column tiles pta_dgemm_launch will use for this shape (callers that update an operand IN PLACE must keep each
+// launch to ONE column tile: pta_potrf_step_ws)
+int pta_dgemm_tile_n(int M, int N, int K, int algo) { return (algo >= 1 && M >= 256 && N >= 128 && K >= 32) ? HBM_T : GBN; }
+
 int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
                      const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,
                      int64_t sA, int64_t sB, int64_t sC, int algo, hipStream_t stream) {

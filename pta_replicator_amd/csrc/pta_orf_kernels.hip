@@ -320,6 +320,7 @@ struct pta_potrf_ctx {
   bool ready = false;
   hipStream_t chain[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_in = nullptr, ev_out[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_diag[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // chain c's first diagonal phase is done
 };
 static thread_local pta_potrf_ctx g_potrf_ctx[PTA_POTRF_MAX_DEVICES];
 
@@ -332,6 +333,7 @@ static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
     for (int i = 0; i < PTA_POTRF_MAX_CHAINS; ++i) {
       PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
       PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
+      PTA_HIP(hipEventCreateWithFlags(&c.ev_diag[i], hipEventDisableTiming));
     }
     PTA_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
     c.ready = true;
@@ -404,6 +406,139 @@ static int pta_potrf_step(double *A, int n, int64_t lda, int64_t strideA, int B,
   return pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
 }
 
+// ---- panel solve through the explicit inverse of the panel's diagonal block (pta_potrf_batched_ws) ---------------------------
+// pta_factor_panel above applies its recursion to the FULL height of a panel: every 64-column solve, K = 64 update and K = 128 /
+// 256 / 512 product touches all rows below - ~1200 dispatches per 68-matrix batch, most of them latency chains that need the whole
+// machine's wave slots to finish in their 40 us and therefore do NOT overlap another chain's trailing update (whose workgroups hold
+// those slots), and 29 % of the flops at K <= 512, where the tile kernel runs at 45-63 TFLOP/s instead of 66.  With a workspace the
+// same panel becomes
+//   (1) the recursion on the nbo x nbo DIAGONAL block only (rows = nbo: a fifth of the work at n = 5000, a few workgroups per
+//       launch - they slip into any free slot);
+//   (2) W = L11^{-1} (lower triangular, nbo x nbo) built from the 64 x 64 inverses k_potf2 parks: 128-blocks by one small kernel,
+//       then block row i from   W[i, <i] = -W_ii (L11[i, <i] W[<i, <i])   - two small products per 128 rows;
+//   (3) X = B W^T for ALL rows below, in place, one 128-column block at a time in DESCENDING order (block j needs B's columns
+//       [0, 128 (j + 1)) only, so the blocks to its right may already hold X): each a tile product with K = 128 (j + 1), flop
+//       count of the triangular solve it replaces;
+//   (4) the trailing update as before (K = nbo).
+// cond(L11) * eps enters X (as it already does through the 64 x 64 inverses): the TD covariances have cond(L) ~ 1e2-1e4, their
+// factors agree with LAPACK to 1e-10 (tests); ill-conditioned inputs take PTA_POTRF_SUBSTITUTION and the workspace-free path.
+
+// one workgroup per (128-column block, matrix): W block = [[X1, 0], [-X2 L21 X1, X2]] from the two 64 x 64 (first block: narrower)
+// diagonal tiles as k_potf2 left them - L below the diagonal, X^T = L^{-T} above it, X's diagonal = 1 / L's.
+__global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A, int64_t lda, int64_t sA, int k0, int nbo, int f128,
+                                                    double *__restrict__ W, int64_t ldw, int64_t sW) {
+  __shared__ double X1[64][65], X2[64][65], L21[64][65], T[64][65];
+  const int blk = blockIdx.x;
+  const int o = blk == 0 ? 0 : f128 + 128 * (blk - 1);     // offset of the block inside the panel
+  const int wd = blk == 0 ? f128 : 128;                     // its width
+  const int w1 = wd > 64 ? wd - 64 : wd, w2 = wd - w1;      // base blocks inside it (w2 = 64 or 0)
+  const double *M = A + (int64_t)blockIdx.y * sA + (int64_t)(k0 + o) * lda + (k0 + o);
+  double *Wb = W + (int64_t)blockIdx.y * sW + (int64_t)o * ldw + o;
+  const int t = threadIdx.x;
+  for (int idx = t; idx < 64 * 64; idx += 256) {
+    const int r = idx >> 6, c = idx & 63;
+    double x1 = 0.0, x2 = 0.0, l = 0.0;
+    if (r < w1 && c < w1) x1 = c < r ? M[(int64_t)c * lda + r] : (c == r ? 1.0 / M[(int64_t)r * lda + r] : 0.0);
+    if (w2) {
+      const double *M2 = M + (int64_t)w1 * lda + w1;
+      x2 = c < r ? M2[(int64_t)c * lda + r] : (c == r ? 1.0 / M2[(int64_t)r * lda + r] : 0.0);
+      if (c < w1) l = M[(int64_t)(w1 + r) * lda + c];
+    }
+    X1[r][c] = x1;
+    X2[r][c] = x2;
+    L21[r][c] = l;
+  }
+  __syncthreads();
+  if (w2) {
+    for (int idx = t; idx < 64 * 64; idx += 256) {  // T = L21 X1
+      const int r = idx >> 6, c = idx & 63;
+      double acc = 0.0;
+      for (int k = c; k < w1; ++k) acc = fma(L21[r][k], X1[k][c], acc);  // X1 lower triangular: k >= c
+      T[r][c] = acc;
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < 128 * 128; idx += 256) {
+    const int r = idx >> 7, c = idx & 127;
+    if (r >= wd || c >= wd) continue;
+    double v = 0.0;
+    if (r < w1) v = c < w1 ? X1[r][c] : 0.0;
+    else if (c >= w1) v = X2[r - w1][c - w1];
+    else {
+      double acc = 0.0;
+      for (int k = 0; k <= r - w1; ++k) acc = fma(X2[r - w1][k], T[k][c], acc);  // X2 lower triangular: k <= r
+      v = -acc;
+    }
+    Wb[(int64_t)r * ldw + c] = v;
+  }
+  // the blocks to the RIGHT of this one (above W's block diagonal) are read by the products that build the block rows below, as part
+  // of the square W[0:oi, 0:oi): they must be zero, and the workspace arrives uninitialised
+  const int right = nbo - (o + wd);
+  for (int64_t idx = t; idx < (int64_t)wd * right; idx += 256) {
+    const int r = (int)(idx / right), c = (int)(idx - (int64_t)r * right);
+    Wb[(int64_t)r * ldw + wd + c] = 0.0;
+  }
+}
+
+#define PTA_POTRF_WS_LD(NBO) ((NBO) + 128)   // leading dimension of W and of the scratch strip: the widest panel is NBO + 127 columns
+
+extern "C" int64_t pta_potrf_workspace_doubles(int n, int B, int flags) {
+  const int nbk = (flags >> 8) & 0xFF;
+  const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;
+  if (n <= NBO || B <= 0 || (flags & (PTA_POTRF_VALU | PTA_POTRF_SUBSTITUTION))) return 0;
+  const int64_t ldw = PTA_POTRF_WS_LD(NBO);
+  return (int64_t)B * (ldw * ldw + 128 * ldw);
+}
+
+// One step of a chain with the workspace scheme; returns the next panel's first column in *k0_io.
+static int pta_potrf_step_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, int *k0_io,
+                             double *W, hipStream_t s, hipEvent_t ev_after_diag) {
+  const int k0 = *k0_io;
+  const int want = (k0 == 0 && n > NBO) ? NBO + (n % 128) : NBO;
+  const int nbo = (n - k0 < want) ? (n - k0) : want;
+  const int pend = k0 + nbo;
+  // (1) the diagonal block: the recursion with the matrix "ending" at the panel's last row
+  int rc = pta_factor_panel(A, pend, lda, strideA, B, k0, nbo, info, flags, algo, s);
+  if (rc != PTA_OK) return rc;
+  *k0_io = pend;
+  const int rows = n - pend;
+  if (rows <= 0) return PTA_OK;
+  const int64_t ldw = PTA_POTRF_WS_LD(NBO), sW = ldw * ldw + 128 * ldw;
+  double *T = W + ldw * ldw;  // [128 x ldw] strip per matrix
+  // (2) W = L11^{-1}
+  const int nb = (nbo + 127) / 128, f128 = nbo - 128 * (nb - 1);  // first block narrower when nbo % 128 != 0
+  hipLaunchKernelGGL(k_inv_blocks, dim3(nb, B), dim3(256), 0, s, A, lda, strideA, k0, nbo, f128, W, ldw, sW);
+  PTA_LAUNCH_CHECK();
+  const double *L11 = A + (int64_t)k0 * lda + k0;
+  for (int i = 1; i < nb; ++i) {
+    const int oi = f128 + 128 * (i - 1);
+    // T = L11[i-rows, 0:oi) . W[0:oi, 0:oi)        (W as the [K x N] operand)
+    rc = pta_dgemm_launch(0, 128, oi, oi, 1.0, L11 + (int64_t)oi * lda, lda, 1, W, ldw, 0.0, T, ldw, 0, B, strideA, sW, sW, 1, s);
+    if (rc != PTA_OK) return rc;
+    // W[i-rows, 0:oi) = -W_ii . T
+    rc = pta_dgemm_launch(0, 128, oi, 128, -1.0, W + (int64_t)oi * ldw + oi, ldw, 1, T, ldw, 0.0, W + (int64_t)oi * ldw, ldw, 0, B, sW, sW, sW, 1, s);
+    if (rc != PTA_OK) return rc;
+  }
+  if (ev_after_diag) PTA_HIP(hipEventRecord(ev_after_diag, s));
+  // (3) X = B W^T in place, 128-column blocks right to left
+  double *Bp = A + (int64_t)pend * lda + k0;
+  for (int j = nb - 1; j >= 0; --j) {
+    const int oj = j == 0 ? 0 : f128 + 128 * (j - 1), wj = j == 0 ? f128 : 128;
+    // in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so a block
+    // the launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left as well
+    const int tile = pta_dgemm_tile_n(rows, wj, oj + wj, algo);
+    for (int c1 = wj; c1 > 0; c1 -= tile) {
+      const int c0 = c1 > tile ? c1 - tile : 0;
+      rc = pta_dgemm_launch(1, rows, c1 - c0, oj + c1, 1.0, Bp, lda, 1, W + (int64_t)(oj + c0) * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B, strideA, sW,
+                            strideA, algo, s);
+      if (rc != PTA_OK) return rc;
+    }
+  }
+  // (4) trailing update
+  double *A22 = A + (int64_t)pend * lda + pend;
+  return pta_dgemm_launch(1, rows, rows, nbo, -1.0, Bp, lda, 1, Bp, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
+}
+
 // Right-looking over panels of NB = 1024 columns; the trailing update of a panel is ONE product with K = NB over the
 // lower-triangular 128 x 128 tiles.  A batch is split into up to four independent CHAINS of matrices, each on its own
 // internal stream: the panel steps of a chain are short, serial and partly memory bound (potf2 on one workgroup per matrix;
@@ -411,16 +546,17 @@ static int pta_potrf_step(double *A, int n, int64_t lda, int64_t strideA, int B,
 // interleave the chains fills one chain's panel phases with another chain's matrix-core work - look-ahead across the batch
 // instead of inside one matrix (an in-matrix look-ahead, next panel on a high-priority stream beside the bulk update, measured
 // slower: it splits every trailing update in two and the concurrent halves slow each other down).
-extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,
-                                    void *stream) {
+static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
+                          int64_t work_doubles, void *stream) {
   PTA_REQUIRE(A && info, PTA_E_ARG, "pta_potrf_batched: NULL argument");
   PTA_REQUIRE(n > 0 && n <= 65535 && B > 0 && B <= 65535, PTA_E_ARG, "pta_potrf_batched: n=%d B=%d", n, B);
   PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
               (long long)lda, (long long)strideA);
   hipStream_t s = pta_stream(stream);
-  // 0: VALU reference GEMM + substitution panel solve (cross-check); 1: MFMA kernels, register-staged operand slabs; 2: the same with
-  // the 128 x 128-tile products' operand slabs brought in by LDS DMA (k_dgemm_glds128)
-  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_GLDS) ? 2 : 1);
+  // 0: VALU reference GEMM + substitution panel solve (cross-check); 2 (default): MFMA kernels, the 128 x 128-tile products' operand
+  // slabs brought in by LDS DMA (k_dgemm_glds128: 66 against 59 TFLOP/s at K = 1024, the whole 68 x 5000^2 batch 56.4 against 60.0
+  // ms); 1 (PTA_POTRF_REG_STAGING): the same products with register-staged slabs (round 2's kernel, kept for the A/B)
+  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_REG_STAGING) ? 1 : 2);
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
@@ -428,10 +564,18 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
   if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
   if (nchain > B) nchain = B;
   if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;
+  // workspace scheme (pta_potrf_batched_ws): panel solves through the explicit inverse of the panel's diagonal block
+  const int64_t need = pta_potrf_workspace_doubles(n, B, flags);
+  const bool use_ws = work != nullptr && need > 0 && work_doubles >= need && algo;
+  const int64_t sWm = use_ws ? need / B : 0;  // workspace doubles per matrix
+  auto chain_step = [&](double *Ab, int Bc, int32_t *infob, double *Wb, int *k0p, hipStream_t st, hipEvent_t ev) {
+    return use_ws ? pta_potrf_step_ws(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, Wb, st, ev)
+                  : pta_potrf_step(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, st);
+  };
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   if (nchain == 1) {
     for (int k0 = 0; k0 < n;) {
-      int rc = pta_potrf_step(A, n, lda, strideA, B, info, flags, algo, NBO, &k0, s);
+      int rc = chain_step(A, B, info, work, &k0, s, nullptr);
       if (rc != PTA_OK) return rc;
     }
   } else {
@@ -449,9 +593,15 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
       for (int c = 0; c < nchain; ++c) {
         if (k0[c] >= n) continue;
         const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
-        if (step == 0) PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
-        rc_chain = pta_potrf_step(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, &k0[c],
-                                  cx->chain[c]);
+        if (step == 0) {
+          PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_in, 0));
+          // workspace scheme: the chains start OUT OF PHASE - chain c begins once chain c - 1 has finished its first diagonal phase - so
+          // that from then on one chain's diagonal phase (a few small, latency-bound kernels) runs beside another's tile products
+          // instead of all chains idling the matrix pipe through their diagonal phases together and then sharing it
+          if (use_ws && c > 0 && !(flags & PTA_POTRF_LOCKSTEP)) PTA_HIP(hipStreamWaitEvent(cx->chain[c], cx->ev_diag[c - 1], 0));
+        }
+        rc_chain = chain_step(A + (int64_t)b0 * strideA, b1 - b0, info + b0, use_ws ? work + (int64_t)b0 * sWm : nullptr, &k0[c], cx->chain[c],
+                              (use_ws && step == 0) ? cx->ev_diag[c] : nullptr);
         if (rc_chain != PTA_OK) break;
         if (k0[c] < n) ++live;
       }
@@ -469,6 +619,16 @@ extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strid
     PTA_LAUNCH_CHECK();
   }
   return PTA_OK;
+}
+
+extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,
+                                    void *stream) {
+  return pta_potrf_impl(A, n, lda, strideA, B, info, flags, nullptr, 0, stream);
+}
+
+extern "C" int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
+                                    int64_t work_doubles, void *stream) {
+  return pta_potrf_impl(A, n, lda, strideA, B, info, flags, work, work_doubles, stream);
 }
 
 extern "C" int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream) {

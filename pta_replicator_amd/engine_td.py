@@ -77,8 +77,14 @@ class TimeDomainMixin:
             b = a
             while b + 1 < P and counts[b + 1] == counts[a]:
                 b += 1
-            _lib.call("pta_potrf_batched_ex", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), counts[a], ld[a],
-                      counts[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, s)
+            # optional workspace of the inverse-based panel solves (include/pta_replicator_amd.h: pta_potrf_batched_ws; 11.8 MB per
+            # matrix, released right after the factorisation).  Off by default: measured 61 ms against 56 ms for the 68 x 5000^2
+            # batch - what it saves in K <= 512 products it loses in the latency chain of the diagonal phase
+            need = int(_lib.lib.pta_potrf_workspace_doubles(counts[a], b - a + 1, flags)) if getattr(self, "td_potrf_workspace", False) else 0
+            work = dv.empty((need,)) if need else None
+            _lib.call("pta_potrf_batched_ws", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), counts[a], ld[a],
+                      counts[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, dv.ptr(work), need, s)
+            del work                                    # stream-ordered: the caching allocator reuses it only behind these kernels
             a = b + 1
         bad = info.cpu().numpy()
         if np.any(bad != 0):

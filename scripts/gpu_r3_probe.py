@@ -45,13 +45,21 @@ if "potrf" in what:
                   dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), s)
     flop = sum(c ** 3 for c in counts) / 3.0
     ref = None
-    for name, flags in (("reg_2chains", 0), ("glds_2chains", _lib.POTRF_GLDS), ("reg_1chain", _lib.POTRF_NO_LOOKAHEAD), ("glds_1chain", _lib.POTRF_GLDS | _lib.POTRF_NO_LOOKAHEAD),
-                        ("glds_4chains", _lib.POTRF_GLDS | _lib.POTRF_CHAINS(4)), ("glds_3chains", _lib.POTRF_GLDS | _lib.POTRF_CHAINS(3))):
+    RS = _lib.POTRF_REG_STAGING
+    need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, 0))
+    work = dv.empty((need,))
+    work.fill_(float("nan"))
+    for name, flags, ws in (("reg_2chains", RS, 0), ("glds_2chains", 0, 0), ("ws_1chain", _lib.POTRF_NO_LOOKAHEAD, 1), ("ws_2chains", 0, 1),
+                            ("ws_2chains_lockstep", _lib.POTRF_LOCKSTEP, 1), ("ws_3chains", _lib.POTRF_CHAINS(3), 1), ("ws_4chains", _lib.POTRF_CHAINS(4), 1),
+                            ("ws_2chains_nb512", _lib.POTRF_NB(2), 2), ("ws_3chains_nb512", _lib.POTRF_NB(2) | _lib.POTRF_CHAINS(3), 2)):
+        if ws == 2:
+            need2 = int(_lib.lib.pta_potrf_workspace_doubles(n, P, flags))
+            work = dv.empty((need2,)); need = need2
         ts = []
         for _ in range(2):
             assemble(); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), flags, s)
+            _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), flags, dv.ptr(work) if ws else None, need if ws else 0, s)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         L0 = eng.d_Ltd[:n * ld].view(n, ld)[:, :n].tril().clone()

@@ -193,13 +193,47 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
     # VALU cross-check, default (MFMA product solves), substitution solves, one chain, 256-wide panels on 3 / 4 chains, and the
-    # LDS-DMA operand staging of the 128-tile updates
+    # register-staged operand slabs of the 128-tile updates (the default stages them by LDS DMA)
     for flags in (lib.POTRF_VALU, 0, lib.POTRF_SUBSTITUTION, lib.POTRF_NO_LOOKAHEAD,
-                  lib.POTRF_CHAINS(3) | lib.POTRF_NB(1), lib.POTRF_CHAINS(4) | lib.POTRF_NB(1), lib.POTRF_GLDS, lib.POTRF_GLDS | lib.POTRF_NB(1)):
+                  lib.POTRF_CHAINS(3) | lib.POTRF_NB(1), lib.POTRF_CHAINS(4) | lib.POTRF_NB(1), lib.POTRF_REG_STAGING, lib.POTRF_REG_STAGING | lib.POTRF_NB(1)):
         L = rn.cholesky_device(dv.f64(A), flags, auto_substitution=False).cpu().numpy()
         ref = np.linalg.cholesky(A)
         assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, flags)
         assert np.all(np.triu(L, 1) == 0)
+
+
+@pytest.mark.parametrize("n,batch,flags", [(1025, 2, 0), (1338, 3, 0), (2500, 2, 0), (2501, 1, 0), (700, 3, "NB1"), (1338, 3, "NB1"), (2500, 2, "NB1C3"),
+                                           (3000, 5, "C4")])
+def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
+    """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
+    over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
+    orders (non-vector operand path), narrow panels (256 columns: many steps, first panel 256 + n % 128 wide) and 3 / 4 chains."""
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    fl = {0: 0, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3), "C4": lib.POTRF_CHAINS(4)}[flags]
+    rng = np.random.default_rng(n + batch)
+    X = rng.standard_normal((batch, n, n + 5))
+    A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
+    ld = n + (n & 1) + 2
+    buf = np.full((batch, n + 1, ld), np.nan)
+    buf[:, :n, :n] = np.tril(A) + np.triu(np.full((n, n), np.nan), 1)     # only the lower triangle is read
+    Ad = dv.f64(buf)
+    info = dv.zeros((batch,), dtype=torch.int32)
+    need = int(lib.lib.pta_potrf_workspace_doubles(n, batch, fl))
+    assert need > 0
+    work = dv.empty((need,))
+    work.fill_(float("nan"))
+    lib.call("pta_potrf_batched_ws", dv.ptr(Ad), n, ld, (n + 1) * ld, batch, dv.ptr(info), fl, dv.ptr(work), need, gpu["s"])
+    assert int(info.abs().sum().item()) == 0
+    L = np.tril(Ad.cpu().numpy()[:, :n, :n])
+    ref = np.linalg.cholesky(A)
+    assert np.all(np.isfinite(L))
+    assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (n, flags)
+    # too small a workspace / none: the workspace-free schedule, same factor
+    Ad2 = dv.f64(buf)
+    lib.call("pta_potrf_batched_ws", dv.ptr(Ad2), n, ld, (n + 1) * ld, batch, dv.ptr(info), fl, dv.ptr(work), need - 1, gpu["s"])
+    L2 = np.tril(Ad2.cpu().numpy()[:, :n, :n])
+    assert np.max(np.abs(L2 - ref)) < 1e-10 * np.max(np.abs(ref))
+    assert int(lib.lib.pta_potrf_workspace_doubles(n, batch, fl | lib.POTRF_SUBSTITUTION)) == 0
 
 
 def test_potrf_not_positive_definite_raises(gpu):

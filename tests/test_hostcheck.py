@@ -162,6 +162,49 @@ def test_orf_basis_device_math_vs_reference_golden(hc):
     assert np.max(np.abs(orf - po.hd_orf_closed_form(locs))) < 1e-14
 
 
+def test_orf_config5_all_pairs_device_math_vs_reference_fixture(hc):
+    """BASELINE.json config 5 at full P: the device ORF formulas (host twin) on all 20 100 pairs against the UNMODIFIED reference's
+    values (tests/golden/c5_orf_lmax4.npz), degree by degree.  l <= 3 at 1e-12 absolute; l = 4 at 2e-12 up to 170 degrees of
+    separation and 2e-10 on the near-antipodal pairs (next test)."""
+    z = load("c5_orf_lmax4.npz")
+    P, lmax, clm = 200, int(z["lmax"]), z["clm"]
+    locs = np.ascontiguousarray(po.psr_locs_equatorial([{"RAJ": z["raj"][a], "DECJ": z["decj"][a]} for a in range(P)]))
+    basis = np.zeros(((lmax + 1) ** 2, P, P))
+    hc.hc_orf_basis(_p(locs, ctypes.c_double), P, lmax, _p(basis, ctypes.c_double))
+    zeta = np.array([[po.calczeta(locs[a, 0], locs[b, 0], locs[a, 1], locs[b, 1]) for b in range(P)] for a in range(P)])
+    for ll in range(lmax + 1):
+        err = np.abs(2 * np.tensordot(clm[ll * ll:(ll + 1) ** 2], basis[ll * ll:(ll + 1) ** 2], axes=1) - z["orf_l"][ll])
+        if ll < 4:
+            assert err.max() < 1e-12, (ll, err.max())
+        else:
+            assert err[np.degrees(zeta) <= 170.0].max() < 2e-12 and err.max() < 2e-10
+    assert np.max(np.abs(2 * np.tensordot(clm, basis, axes=1) - z["orf"])) < 2e-10
+
+
+def test_orf_l4_near_antipodal_pairs_are_ill_conditioned_in_the_reference(hc):
+    """Why the l = 4 basis is held to 2e-10 (not 1e-12) on near-antipodal pairs: at the worst pair of config 5 (pulsars 25 / 33,
+    174.86 degrees apart) the reference's computational-frame sums (spharmORFbasis.py:43-248) cancel ~6 digits.  Evaluated with
+    the reference's formula in float64 - the restatement is bit-identical to the reference there - and in longdouble, the
+    reference's OWN result is 1e-10 from the better one; the device formulas land 2.3e-10 from it, 1.4e-10 from the reference."""
+    z = load("c5_orf_lmax4.npz")
+    locs = np.ascontiguousarray(po.psr_locs_equatorial([{"RAJ": z["raj"][a], "DECJ": z["decj"][a]} for a in (25, 33)]))
+    p1, p2, t1, t2 = locs[0, 0], locs[1, 0], locs[0, 1], locs[1, 1]
+    zeta, ll = po.calczeta(p1, p2, t1, t2), 4
+    assert abs(np.degrees(zeta) - 174.857) < 1e-3
+
+    def row(zz):
+        plus = [po.arbCompFrame_ORF(mm, ll, zz) for mm in range(ll + 1)]
+        gamma_ml = [(-1) ** mm * plus[mm] for mm in range(1, ll + 1)][::-1] + plus
+        return np.array([float(po.real_rotated_Gammas(mi - ll, ll, p1, p2, t1, t2, gamma_ml)) for mi in range(2 * ll + 1)])
+    b64, b80 = row(zeta), row(np.longdouble(zeta))
+    basis = np.zeros((25, 2, 2))
+    hc.hc_orf_basis(_p(locs, ctypes.c_double), 2, 4, _p(basis, ctypes.c_double))
+    dev = basis[16:25, 0, 1]
+    ref_noise, dev_err = np.max(np.abs(b64 - b80)), np.max(np.abs(dev - b80))
+    assert 5e-11 < ref_noise < 3e-10, ref_noise           # the reference's own float64 rounding at this pair
+    assert dev_err < 4e-10 and np.max(np.abs(dev - b64)) < 2e-10
+
+
 def test_orf_hd_headline_array(hc):
     """68 isotropic pulsars (config 3 geometry): closed form == general basis, and is positive definite."""
     rng = np.random.default_rng(68)
