@@ -3,6 +3,7 @@
 // such path; the covariance is the one implied by its RN/WN/ECORR synthesis (App. A.1):
 //   C[i,j] = sum_c phi[c] F[i,c] F[j,c] + (i==j) sigma2[i] + (epoch_i == epoch_j) ecorr2[i]
 // (red_noise.py:98-101,126-128; white_noise.py:105-109,182).
+#include <type_traits>
 #include "pta_common.h"
 #include "pta_mfma.h"
 #include "pta_rng.h"
@@ -291,11 +292,24 @@ extern "C" int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z,
 #define TDS_NT (TDS_N / 16)
 #define TDS_MANY_ITEMS 64  // from this many strips on, whole strips are dealt to the XCDs (see the work item order below)
 
+// Operand path (round 3): the strip of L is brought in by LDS DMA (global_load_lds_dwordx4, 16 bytes per lane straight into LDS; no
+// staging registers, no ds_write pass, no s_waitcnt vmcnt(0) in front of it) as a row-major, unpadded slab image - 256 rows x 16 k =
+// 128 bytes per row - whose 16-byte chunks are XOR-swizzled per row (pta_gl_f below: the source address carries the swizzle, the DMA
+// writes lane-linearly) so that the fragment reads are conflict-free ds_read_b128: with k = 4 q + st a lane's four B values of a
+// column tile are 32 contiguous bytes = two reads instead of four ds_read_b64.  Elements above L's diagonal hold scratch (the
+// factorisation parks inverses there) and are masked in registers, in the slabs that cross the strip's diagonal block only.
+// One barrier per slab; the DMA of slab s + 1 is issued behind the first MFMAs of slab s and waited for at its closing barrier.
+#define TDS_ROWB 128                      // bytes per LDS row
+__device__ __forceinline__ int pta_td_swz(int row) {
+  const int e = (row >> 1) & 7;           // see pta_gemm.hip (k_dgemm_glds128): chunk c of row r lives in slot c ^ f(r)
+  return (e & 1) | (((e >> 2) & 1) * 6);
+}
+
 template <bool FAST>
 __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t seed, uint64_t r0, int M, double *__restrict__ out,
                                                         int64_t ld_out) {
   constexpr int fast = FAST ? 1 : 0;
-  __shared__ double Bs[2][TDS_K][TDS_LD];
+  __shared__ double __attribute__((aligned(256))) Bs[2][TDS_N * TDS_K];  // [stage][row * 16 + k], chunks swizzled per row: 2 x 32 KB
   // work item order: items are sorted by decreasing K extent (host); consecutive workgroups go to the 8 XCDs round-robin, so
   // XCD x takes items x, x + 8, ... (each XCD gets the same mix of long and short strips) and walks the Z-row groups of one
   // item back to back: the strip of L is fetched into ONE L2 and re-read there by the other row groups.
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   const int c = l & 15, q = l >> 4;
   const int kend = min(n, n0 + TDS_N);  // L[i, j] = 0 for j > i: columns beyond the strip's last row contribute nothing
   const int nslab = (kend + TDS_K - 1) / TDS_K;
+  typedef double pta_f64x2 __attribute__((ext_vector_type(2)));
 
   // the Z row of this lane's A operand: m = realisation (rows_per_real == 1) or (realisation, pulsar) of the grid factor
   const int m_a = mg * TDS_M + wv * 16 + c;
@@ -334,59 +349,67 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
 #pragma unroll
   for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
 
-  // global -> register fetch of one slab: rows wv * 64 + c + 16 g (g < 4), k pairs q + 4 h (h < 2), as double2
-  double2 rg[8];
-  auto fetch = [&](int k0) {
+  // DMA side: wave wv stages rows [64 wv, 64 wv + 64) of the strip, 8 rows per instruction (lane -> row l >> 3, slot l & 7).  Rows
+  // past the factor's last one re-read it (their outputs are never stored); a chunk past the row's pitch is clamped into it (it
+  // lies above the diagonal and is masked).
+  const int row0 = n0 + 64 * wv + (l >> 3);  // row of the factor this lane fetches in instruction g: row0 + 8 g, clamped (addresses
+                                             // are formed at issue: eight 64-bit pointers would cost 16 VGPRs the accumulators need)
+  const int kmax = (int)ldl - 2;
+  auto stage = [&](int k0, int st) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = n0 + wv * 64 + c + 16 * g;
-        const int k = k0 + 2 * (q + 4 * h);
-        double2 v = make_double2(0.0, 0.0);
-        if (row < n) {
-          const double *p = L + (int64_t)row * ldl + k;
-          if (k + 1 <= row)
-            v = *reinterpret_cast<const double2 *>(p);  // both columns on or below the diagonal
-          else if (k == row)
-            v.x = *p;                                    // the diagonal element; the one right of it counts as zero
-        }
-        rg[2 * g + h] = v;
-      }
+    for (int g = 0; g < 8; ++g) {
+      // chunk of the row that belongs in slot l & 7: (l & 7) ^ f(row), f from (row >> 1) & 7 = (4 g + (l >> 4)) & 7
+      const int e = (4 * g + (l >> 4)) & 7;
+      const int kcg = 2 * ((l & 7) ^ ((e & 1) | (((e >> 2) & 1) * 6)));
+      char *dst = reinterpret_cast<char *>(&Bs[st][0]) + (64 * wv + 8 * g) * TDS_ROWB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L + (int64_t)min(row0 + 8 * g, n - 1) * ldl + min(k0 + kcg, kmax)),
+                                       (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    }
   };
-  auto stash = [&](int buf) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int row = wv * 64 + c + 16 * g, kk = 2 * (q + 4 * h);
-        Bs[buf][kk][row] = rg[2 * g + h].x;
-        Bs[buf][kk + 1][row] = rg[2 * g + h].y;
-      }
-  };
-  fetch(0);
-  stash(0);
-  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
-  __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    const int cur = s & 1;
-    const int k0 = s * TDS_K;
-    if (s + 1 < nslab) fetch(k0 + TDS_K);
+  // fragment side: column tile j = rows 16 j + c of the strip; chunks 2 q (k = 4 q, 4 q + 1) and 2 q + 1 (k = 4 q + 2, 4 q + 3)
+  const int fsw = pta_td_swz(c);
+  const int offc = c * TDS_ROWB, c0 = ((2 * q) ^ fsw) * 16, c1 = ((2 * q + 1) ^ fsw) * 16;
+
+  // one slab: two Box-Muller pairs (this lane's four deviates), 32 fragment reads, 64 MFMAs.  MASK: the slab crosses the strip's
+  // diagonal block - entries with k > row are not part of L
+  auto slab = [&](int s, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
+    const int cur = s & 1, k0 = s * TDS_K;
+    const char *pb = reinterpret_cast<const char *>(&Bs[cur][0]) + offc;
     double z[4];
     const uint32_t p0 = (uint32_t)((k0 >> 1) + 2 * q);
     pta_normal_pair(seed, real_a, strm_a, p0, z[0], z[1], fast);
     pta_normal_pair(seed, real_a, strm_a, p0 + 1u, z[2], z[3], fast);
+    const int kq = k0 + 4 * q;  // this lane's first k of the slab
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      double b[TDS_NT];
+    for (int half = 0; half < 2; ++half) {
+      pta_f64x2 b[TDS_NT];
 #pragma unroll
-      for (int j = 0; j < TDS_NT; ++j) b[j] = Bs[cur][4 * q + st][16 * j + c];
+      for (int j = 0; j < TDS_NT; ++j) b[j] = *reinterpret_cast<const pta_f64x2 *>(pb + j * 16 * TDS_ROWB + (half ? c1 : c0));
+      if (MASK) {
 #pragma unroll
-      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[st], b[j], acc[j]);
+        for (int j = 0; j < TDS_NT; ++j) {
+          const int row = n0 + 16 * j + c;
+          b[j].x = (kq + 2 * half <= row) ? b[j].x : 0.0;
+          b[j].y = (kq + 2 * half + 1 <= row) ? b[j].y : 0.0;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[2 * half], b[j].x, acc[j]);
+      if (half == 0 && s + 1 < nslab) stage(k0 + TDS_K, cur ^ 1);  // behind the first 16 MFMAs; its buffer was last read before the previous barrier
+#pragma unroll
+      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[2 * half + 1], b[j].y, acc[j]);
     }
-    if (s + 1 < nslab) stash(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the closing barrier (and its vmcnt(0)) behind the MFMAs
     __syncthreads();
-  }
+  };
+  stage(0, 0);
+  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  __syncthreads();
+  const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 256)
+  int s = 0;
+  for (; s < min(sdiag, nslab); ++s) slab(s, std::false_type{});
+  for (; s < nslab; ++s) slab(s, std::true_type{});
 
   // epilogue: lane holds rows (Z rows) q + 4 reg of the wave's 16 and column 16 j + c of the strip
   const bool epi = pl.gw_G != nullptr;
