@@ -168,6 +168,72 @@ def cpu_baseline(psrs, noise, subset=8, repeats=3):
             "value_without_ecorr": 1.0 / best["seconds_without_ecorr"], "host_cpus": ncpu}
 
 
+def api_mode_timing(psrs, noise, repeats=2):
+    """ONE realisation of the bench array through the drop-in add_* API (replay mode: NumPy legacy draws on the host in the
+    reference's order, host-owned pulsar objects, PCIe both ways), in ms: `loop` = the reference's usage, one call per pulsar and
+    signal (tests/test_against_libstempo.py:25-53, notebook cell 9); `list` = the same calls given the pulsar list (one launch per
+    signal, per-pulsar legacy streams drawn on host threads).  `host_rng_ms` = what np.random alone costs for these draws on this
+    host, single thread - the floor of the loop form."""
+    import torch
+    from pta_replicator_amd.simulate import make_ideal
+    from pta_replicator_amd.white_noise import add_measurement_noise, add_jitter
+    from pta_replicator_amd.red_noise import add_red_noise, add_gwb
+    P = len(psrs)
+    s_wn, s_ec, s_rn = [10660 + i for i in range(P)], [17763 + i for i in range(P)], [19870 + i for i in range(P)]
+
+    def run(style):
+        for p in psrs:
+            make_ideal(p)
+        t = {}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        add_gwb(psrs, noise["gw_log10_A"], 13. / 3., seed=16672)
+        torch.cuda.synchronize(); t["gwb"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        if style == "loop":
+            for ii, p in enumerate(psrs):
+                add_measurement_noise(p, efac=noise["efac"][ii], log10_equad=noise["log10_equad"][ii], flags=noise["flags"][ii], seed=s_wn[ii])
+        else:
+            add_measurement_noise(psrs, efac=noise["efac"], log10_equad=noise["log10_equad"], flags=noise["flags"], seed=s_wn)
+        torch.cuda.synchronize(); t["wn"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        if style == "loop":
+            for ii, p in enumerate(psrs):
+                add_jitter(p, log10_ecorr=noise["log10_ecorr"][ii], flags=noise["flags"][ii], coarsegrain=0.1, seed=s_ec[ii])
+        else:
+            add_jitter(psrs, log10_ecorr=noise["log10_ecorr"], flags=noise["flags"], coarsegrain=0.1, seed=s_ec)
+        torch.cuda.synchronize(); t["ecorr"] = time.perf_counter() - t0; t0 = time.perf_counter()
+        if style == "loop":
+            for ii, p in enumerate(psrs):
+                if noise["rn_log10_A"][ii] is not None:
+                    add_red_noise(p, noise["rn_log10_A"][ii], noise["rn_gamma"][ii], components=30, seed=s_rn[ii])
+        else:
+            add_red_noise(psrs, noise["rn_log10_A"], noise["rn_gamma"], components=30, seed=s_rn)
+        torch.cuda.synchronize(); t["rn"] = time.perf_counter() - t0
+        t["total"] = sum(t.values())
+        return t, np.concatenate([p.residuals.resids_value for p in psrs])
+
+    out = {}
+    res = {}
+    for style in ("loop", "list"):
+        run(style)                                       # warm-up (flag index caches, pinned buffers)
+        best = None
+        for _ in range(repeats):
+            t, r = run(style)
+            if best is None or t["total"] < best["total"]:
+                best = t
+        out[style] = {k: round(v * 1e3, 3) for k, v in best.items()}
+        res[style] = r
+    out["list_equals_loop"] = bool(np.array_equal(res["loop"], res["list"]))
+    t0 = time.perf_counter()
+    np.random.seed(1)
+    Nf = 3000
+    for p in psrs:
+        n = p.toas.ntoas
+        np.random.randn(Nf); np.random.randn(Nf); np.random.randn(n); np.random.randn(n); np.random.randn(n); np.random.randn(60)
+    out["host_rng_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    for p in psrs:
+        make_ideal(p)
+    return out
+
+
 def td_mode_numbers(eng, R):
     """BASELINE.json's secondary metric on the SAME array: the dense time-domain path (no counterpart in the reference) -
     covariance assembly, batched blocked fp64 Cholesky (MFMA trailing update), then whole-array realisations/s of generate_td
@@ -532,6 +598,13 @@ def main():
         line["td_mode"] = td
     if cfg4 is not None:
         line["config4_shape"] = cfg4
+    if world == 1:
+        try:
+            api = api_mode_timing(psrs, noise)
+            line["api_mode_ms"] = api["loop"]["total"]
+            line["api_mode"] = api
+        except Exception as e:  # pragma: no cover
+            line["api_mode"] = {"error": str(e)[:300]}
     if world > 1 and not args.no_gather:
         gather_phase(line)
     if world == 1 and not args.no_cpu_baseline:

@@ -63,35 +63,93 @@ def create_fourier_design_matrix_red(toas, nmodes=30, Tspan=None, logf=False, fm
     return Ft.T.contiguous().cpu().numpy(), np.repeat(f, 2)
 
 
-def add_red_noise(psr, log10_amplitude, spectral_index, components=30, seed=None, modes=None, Tspan=None,
-                  libstempo_convention=False):
-    """Add red noise with P(f) = A^2 / (12 pi^2) (f year)^-gamma using `components` Fourier bases
-    (red_noise.py:106-135).  The `Tspan` argument is ignored, as in the reference (:124)."""
+def _red_noise_inputs(psr, log10_amplitude, spectral_index, components, modes):
+    """toas [s], sampling frequencies and sqrt(prior) of one pulsar, with the reference's expressions (red_noise.py:112-126)."""
     A = 10 ** log10_amplitude
     gamma = spectral_index
     fyr = 1 / YEAR_IN_SEC
-    if seed is not None:
-        np.random.seed(seed)
-    if modes is not None:
-        print("Must use linear spacing.")
     toas = np.array(psr.toas.table["tdbld"], dtype="float64") * DAY_IN_SEC
     Tspan = toas.max() - toas.min()
     f = _fourier_frequencies(toas, components, Tspan, False, None, None, modes)
     freqs = np.repeat(f, 2)
     prior = A ** 2 * (freqs / fyr) ** (-gamma) / (12 * np.pi ** 2 * Tspan) * YEAR_IN_SEC ** 3
-    y = np.sqrt(prior) * np.random.randn(freqs.size)
+    return toas, f, np.sqrt(prior)
 
-    n, K = len(toas), len(freqs)
-    Ft = _design_matrix_device(toas, f, None, libstempo_convention)
-    y_d = dv.f64(y)
-    out = dv.empty((1, n))
-    _lib.call("pta_rn_synth", dv.ptr(Ft), n, n, K, dv.ptr(y_d), K, 1, dv.ptr(out), n, 0, dv.stream_ptr())
-    dt = out[0].cpu().numpy() * u.s
 
+def _record_red_noise(psr, log10_amplitude, spectral_index, dt):
     psr.update_added_signals("{}_red_noise".format(psr.name),
                              {"amplitude": log10_amplitude, "spectral_index": spectral_index}, dt)
     psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
     psr.update_residuals()
+
+
+def add_red_noise(psr, log10_amplitude, spectral_index, components=30, seed=None, modes=None, Tspan=None,
+                  libstempo_convention=False):
+    """Add red noise with P(f) = A^2 / (12 pi^2) (f year)^-gamma using `components` Fourier bases
+    (red_noise.py:106-135).  The `Tspan` argument is ignored, as in the reference (:124).
+
+    ``psr`` may be a LIST of pulsars with per-pulsar ``log10_amplitude`` / ``spectral_index`` / ``seed`` lists (an amplitude of
+    None skips that pulsar): the loop of single calls with one upload, one download and no synchronisation in between."""
+    if isinstance(psr, (list, tuple)):
+        return _add_red_noise_list(list(psr), log10_amplitude, spectral_index, components, seed, modes, libstempo_convention)
+    if seed is not None:
+        np.random.seed(seed)
+    if modes is not None:
+        print("Must use linear spacing.")
+    toas, f, amp = _red_noise_inputs(psr, log10_amplitude, spectral_index, components, modes)
+    y = amp * np.random.randn(amp.size)
+    n, nm, K = len(toas), len(f), amp.size
+    t_d, f_d, y_d = dv.upload_packed([toas, f, y])
+    Ft = dv.empty((K, n))
+    t_ref = float(toas[0]) if libstempo_convention else 0.0
+    s = dv.stream_ptr()
+    _lib.call("pta_rn_basis", dv.ptr(t_d), n, ctypes.c_double(t_ref), dv.ptr(f_d), None, nm, 1 if libstempo_convention else 0, dv.ptr(Ft), n, s)
+    out = dv.empty((1, n))
+    _lib.call("pta_rn_synth", dv.ptr(Ft), n, n, K, dv.ptr(y_d), K, 1, dv.ptr(out), n, 0, s)
+    _record_red_noise(psr, log10_amplitude, spectral_index, dv.download(out[0]) * u.s)
+
+
+def _add_red_noise_list(psrs, log10_amplitude, spectral_index, components, seed, modes, libstempo_convention):
+    P = len(psrs)
+    lA = list(log10_amplitude) if isinstance(log10_amplitude, (list, tuple, np.ndarray)) else [log10_amplitude] * P
+    gm = list(spectral_index) if isinstance(spectral_index, (list, tuple, np.ndarray)) else [spectral_index] * P
+    seeds = None if seed is None else list(seed)
+    if len(lA) != P or len(gm) != P or (seeds is not None and len(seeds) != P):
+        raise ValueError("log10_amplitude / spectral_index / seed must be scalars or one entry per pulsar")
+    if modes is not None:
+        print("Must use linear spacing.")
+    live = [a for a in range(P) if lA[a] is not None and gm[a] is not None]
+    inp = [_red_noise_inputs(psrs[a], lA[a], gm[a], components, modes) for a in live]
+    if seeds is None:
+        ys = [amp * np.random.randn(amp.size) for (_, _, amp) in inp]
+    else:   # every pulsar re-seeds: its 2 * components draws are the head of the stream np.random.seed(seed_a) starts
+        ys = []
+        for a, (_, _, amp) in zip(live, inp):
+            rs = np.random.RandomState(seeds[a])
+            ys.append(amp * rs.randn(amp.size))
+        if live:
+            np.random.set_state(rs.get_state())
+    counts = [len(t) for (t, _, _) in inp]
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    dev = dv.upload_packed([np.concatenate([t for (t, _, _) in inp])] + [x for (_, f, _) in inp for x in (f,)] + ys) if live else []
+    t_all = dev[0] if live else None
+    out = dv.empty((1, int(off[-1]))) if live else None
+    s = dv.stream_ptr()
+    keep = []
+    for k, a in enumerate(live):
+        toas, f, amp = inp[k]
+        n, nm, K = len(toas), len(f), amp.size
+        f_d, y_d = dev[1 + k], dev[1 + len(live) + k]
+        Ft = dv.empty((K, n))
+        keep.append(Ft)
+        t_ref = float(toas[0]) if libstempo_convention else 0.0
+        tp = ctypes.c_void_p(t_all.data_ptr() + 8 * int(off[k]))
+        _lib.call("pta_rn_basis", tp, n, ctypes.c_double(t_ref), dv.ptr(f_d), None, nm, 1 if libstempo_convention else 0, dv.ptr(Ft), n, s)
+        _lib.call("pta_rn_synth", dv.ptr(Ft), n, n, K, dv.ptr(y_d), K, 1, ctypes.c_void_p(out.data_ptr() + 8 * int(off[k])), n, 0, s)
+    if live:
+        res = dv.download(out[0])
+        for k, a in enumerate(live):
+            _record_red_noise(psrs[a], lA[a], gm[a], res[off[k]:off[k + 1]] * u.s)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -43,15 +43,26 @@ class _Scalar:
 
 
 class ArrayResiduals:
-    """time residuals of an idealised pulsar: total injected delay, weighted-mean subtracted (PINT's default)."""
+    """time residuals of an idealised pulsar: total injected delay, weighted-mean subtracted (PINT's default).
+
+    A snapshot, like ``pint.residuals.Residuals``: it keeps the accumulated-shift column as it was when the object was built
+    (ArrayTOAs.adjust_TOAs REPLACES that array, never mutates it) and evaluates ``resids_value`` on first access - an injection
+    loop that rebuilds the residuals after every add_* (simulate.py:40-42) pays for the arithmetic only when somebody looks."""
 
     def __init__(self, toas):
         # the accumulated shift is tracked on its own: differencing two longdouble MJDs (resolution 2.5e-10 s at
         # MJD 53000) would bury the 1e-10-relative parity this package is tested to
-        shift = (toas.shift_day_ld * np.longdouble(86400)).astype(np.float64)
-        w = 1.0 / toas.errors_us ** 2
-        self.resids_value = shift - np.sum(shift * w) / np.sum(w)
+        self._shift_day_ld = toas.shift_day_ld
         self._err_us = toas.errors_us
+        self._resids = None
+
+    @property
+    def resids_value(self):
+        if self._resids is None:
+            shift = (self._shift_day_ld * np.longdouble(86400)).astype(np.float64)
+            w = 1.0 / self._err_us ** 2
+            self._resids = shift - np.sum(shift * w) / np.sum(w)
+        return self._resids
 
     @property
     def time_resids(self):

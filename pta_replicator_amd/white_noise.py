@@ -6,6 +6,13 @@ the (realisation-independent) epoch bucketing stay on the host - the latter in n
 (pta_quantize_epochs) - while the per-TOA arithmetic runs in HIP kernels.  ECORR is a gather through the epoch
 map instead of the reference's dense N x E indicator matrix (17 s of its 18.6 s per realisation at 68 x 5000).
 ``add_efac`` / ``add_equad`` / ``add_ecorr`` are libstempo-style aliases.
+
+Latency of a call: the flag column of a pulsar is indexed ONCE (``flag_codes``: unique labels + integer codes,
+cached on the TOA object) instead of being rebuilt as a string array per call; the operands of a call travel in one pinned staging
+copy and the result in one (device.upload_packed / download).  Both functions also accept a LIST of pulsars (with per-pulsar
+parameter lists and a list of seeds): one upload, one launch over the concatenated TOAs and one download per signal, every
+pulsar's draws exactly the stream ``np.random.seed(seed_i)`` would give.  What remains of a call is host work that the parity
+contract pins: the NumPy legacy draws themselves (14 ms per 68 x 5000 realisation) and the per-pulsar longdouble TOA bookkeeping.
 """
 import ctypes
 
@@ -46,16 +53,56 @@ def quantize_fast(times, flags=None, dt=1.0):
     return avetoas, U
 
 
-def add_measurement_noise(psr, efac=1.0, log10_equad=None, flagid="f", flags=None, seed=None, tnequad=False):
-    """Add EFAC/EQUAD white noise (white_noise.py:47-125): EFAC*(sigma z1 + EQUAD z2) by default,
-    EFAC*sigma z1 + EQUAD z2 with ``tnequad``.  z2 is drawn even when EQUAD is zero, like the reference."""
-    equad_str = "tnequad" if tnequad else "t2equad"
-    if log10_equad is not None:
-        equad = 10 ** log10_equad
-    else:
-        equad = 0.0
-    if seed is not None:
-        np.random.seed(seed)
+def flag_codes(toas, flagid):
+    """(labels, codes): ``labels[codes[i]]`` is the value of flag ``flagid`` of TOA i - what the reference rebuilds on every call
+    as ``np.array([f[flagid] for f in toas.table['flags'].data])`` (white_noise.py:98-99,161; half of a call's time at 5000 TOAs).
+    Built once per (TOA object, flagid) and cached on the object; flags are injection-invariant (adjust_TOAs does not touch them).
+    The cache is keyed by the TOA count and spot-checked against the live flags (first / middle / last TOA)."""
+    data = toas.table["flags"].data
+    n = len(data)
+    cache = getattr(toas, "_pta_flag_codes", None)
+    hit = cache.get(flagid) if isinstance(cache, dict) else None
+    if hit is not None and hit[0] == n and all(str(hit[1][hit[2][i]]) == str(data[i][flagid]) for i in {0, n // 2, n - 1}):
+        return hit[1], hit[2]
+    col = np.array([f[flagid] for f in data])
+    labels, codes = np.unique(col, return_inverse=True)
+    codes = codes.astype(np.int32)
+    try:
+        if not isinstance(cache, dict):
+            cache = {}
+            toas._pta_flag_codes = cache
+        cache[flagid] = (n, labels, codes)
+    except AttributeError:      # an object that refuses new attributes: no cache, same result
+        pass
+    return labels, codes
+
+
+def _per_flag_vector(labels, codes, flags, values):
+    """vec[i] = values[ct] where TOA i's flag == flags[ct], else 0 - the loop of white_noise.py:100-103 through the label table
+    (a later entry of `flags` overrides an earlier one, as in the reference's in-order assignment)."""
+    lut = np.zeros(len(labels))
+    for ct, flag in enumerate(flags):
+        lut[flag == labels] = values[ct]
+    return lut[codes]
+
+
+def errors_seconds(toas):
+    """TOA uncertainties in seconds as float64 (white_noise.py:105: ``get_errors().to('s')``), converted once per TOA object - the
+    errors are injection-invariant - and cached on it (keyed by the TOA count)."""
+    n = toas.ntoas
+    hit = getattr(toas, "_pta_errors_s", None)
+    if hit is not None and len(hit) == n:
+        return hit
+    sig = np.asarray(toas.get_errors().to("s").value, dtype=np.float64)
+    try:
+        toas._pta_errors_s = sig
+    except AttributeError:
+        pass
+    return sig
+
+
+def _wn_vectors(psr, efac, equad, flagid, flags):
+    """efacvec, equadvec of one pulsar with the reference's checks and messages (white_noise.py:83-103)."""
     ntoas = psr.toas.ntoas
     efacvec = np.zeros(ntoas)
     equadvec = np.zeros(ntoas)
@@ -66,23 +113,41 @@ def add_measurement_noise(psr, efac=1.0, log10_equad=None, flagid="f", flags=Non
         equadvec = np.ones(ntoas) * equad
     if (flags is not None and not np.isscalar(efac)) or (flags is not None and not np.isscalar(equad)):
         if len(efac) == len(flags) and len(equad) == len(flags):
-            toa_flags = np.array([f[flagid] for f in psr.toas.table["flags"].data])
-            for ct, flag in enumerate(flags):
-                ind = flag == toa_flags
-                efacvec[ind] = efac[ct]
-                equadvec[ind] = equad[ct]
+            labels, codes = flag_codes(psr.toas, flagid)
+            efacvec = _per_flag_vector(labels, codes, flags, efac)
+            equadvec = _per_flag_vector(labels, codes, flags, equad)
         else:
             raise ValueError("ERROR: flags must be same length as efac and log10_equad")
+    return efacvec, equadvec
 
-    sigma = np.asarray(psr.toas.get_errors().to("s").value, dtype=np.float64)
-    z1 = np.random.randn(ntoas)
-    z2 = np.random.randn(ntoas)
-    sig_d, ef_d, eq_d, z1_d, z2_d = dv.f64(sigma), dv.f64(efacvec), dv.f64(equadvec), dv.f64(z1), dv.f64(z2)
-    out = dv.empty((1, ntoas))
-    _lib.call("pta_wn", dv.ptr(sig_d), dv.ptr(ef_d), dv.ptr(eq_d), ntoas, 1 if tnequad else 0, dv.ptr(z1_d), dv.ptr(z2_d),
-              ntoas, 1, dv.ptr(out), ntoas, 0, dv.stream_ptr())
-    dt = out[0].cpu().numpy() * u.s
 
+def _legacy_normals(seeds, counts):
+    """One list of NumPy legacy-stream normal arrays per pulsar: pulsar i draws ``randn(c)`` for c in counts[i], in order, from the
+    stream ``np.random.seed(seeds[i])`` starts (white_noise.py:79-80,105-109,154-155,182), through ``RandomState(seed)`` - the same
+    MT19937 + legacy polar Gaussian, value for value - and the GLOBAL stream is left where the sequential calls would leave it: in
+    the state after the last pulsar's draws.  ``seeds is None``: the global stream continues through the pulsars in order, like a
+    loop of reference calls with seed=None.  (Drawn on one thread: the legacy generator holds the GIL - a thread pool measured 2.3x
+    SLOWER than the serial loop; these draws, 14 ms per 68 x 5000 realisation, are the floor of replay mode.)"""
+    if seeds is None:
+        return [[np.random.randn(int(c)) for c in cs] for cs in counts]
+    out, rs = [], None
+    for seed, cs in zip(seeds, counts):
+        rs = np.random.RandomState(seed)
+        out.append([rs.randn(int(c)) for c in cs])
+    if rs is not None:
+        np.random.set_state(rs.get_state())
+    return out
+
+
+def _broadcast(val, P, what):
+    if isinstance(val, (list, tuple)) and len(val) == P:
+        return list(val)
+    if val is None or np.isscalar(val):
+        return [val] * P
+    raise ValueError(f"{what}: expected a scalar or one entry per pulsar ({P})")
+
+
+def _record_wn(psr, efac, log10_equad, flags, equad_str, dt):
     if flags is None:
         psr.update_added_signals("{}_measurement_noise".format(psr.name),
                                  {"efac": efac, "log10_" + equad_str: log10_equad}, dt)
@@ -95,14 +160,65 @@ def add_measurement_noise(psr, efac=1.0, log10_equad=None, flagid="f", flags=Non
     psr.update_residuals()
 
 
-def add_jitter(psr, log10_ecorr, flagid="f", flags=None, coarsegrain=0.1, seed=None):
-    """Add correlated (ECORR) noise of rms ecorr [s] per epoch, epochs = greedy buckets of width ``coarsegrain``
-    days (white_noise.py:128-198)."""
-    ecorr = 10 ** log10_ecorr
+def add_measurement_noise(psr, efac=1.0, log10_equad=None, flagid="f", flags=None, seed=None, tnequad=False):
+    """Add EFAC/EQUAD white noise (white_noise.py:47-125): EFAC*(sigma z1 + EQUAD z2) by default,
+    EFAC*sigma z1 + EQUAD z2 with ``tnequad``.  z2 is drawn even when EQUAD is zero, like the reference.
+
+    ``psr`` may be a LIST of pulsars; ``efac`` / ``log10_equad`` / ``flags`` / ``seed`` are then one entry per pulsar (or one value
+    for all; ``flags`` a list of flag lists): equivalent to the loop of single calls, in one launch."""
+    if isinstance(psr, (list, tuple)):
+        return _add_measurement_noise_list(list(psr), efac, log10_equad, flagid, flags, seed, tnequad)
+    equad_str = "tnequad" if tnequad else "t2equad"
+    if log10_equad is not None:
+        equad = 10 ** log10_equad
+    else:
+        equad = 0.0
     if seed is not None:
         np.random.seed(seed)
-    times = np.asarray(psr.toas.get_mjds().value, dtype=np.float64)
-    epoch_of, first = epoch_map(times, coarsegrain)
+    ntoas = psr.toas.ntoas
+    efacvec, equadvec = _wn_vectors(psr, efac, equad, flagid, flags)
+    sigma = errors_seconds(psr.toas)
+    z1 = np.random.randn(ntoas)
+    z2 = np.random.randn(ntoas)
+    sig_d, ef_d, eq_d, z1_d, z2_d = dv.upload_packed([sigma, efacvec, equadvec, z1, z2])
+    out = dv.empty((1, ntoas))
+    _lib.call("pta_wn", dv.ptr(sig_d), dv.ptr(ef_d), dv.ptr(eq_d), ntoas, 1 if tnequad else 0, dv.ptr(z1_d), dv.ptr(z2_d),
+              ntoas, 1, dv.ptr(out), ntoas, 0, dv.stream_ptr())
+    dt = dv.download(out[0]) * u.s
+    _record_wn(psr, efac, log10_equad, flags, equad_str, dt)
+
+
+def _add_measurement_noise_list(psrs, efac, log10_equad, flagid, flags, seed, tnequad):
+    P = len(psrs)
+    equad_str = "tnequad" if tnequad else "t2equad"
+    efacs, l10s = _broadcast(efac, P, "efac"), _broadcast(log10_equad, P, "log10_equad")
+    if flags is not None and (len(flags) != P or not all(f is None or isinstance(f, (list, tuple, np.ndarray)) for f in flags)):
+        raise ValueError("flags must be a per-pulsar list of flag lists")
+    flagl = flags if flags is not None else [None] * P
+    seeds = None if seed is None else list(seed)
+    if seeds is not None and len(seeds) != P:
+        raise ValueError("seed must be None or one seed per pulsar")
+    counts = [p.toas.ntoas for p in psrs]
+    vecs = []
+    for a, p in enumerate(psrs):
+        equad = 10 ** np.asarray(l10s[a], dtype=float) if l10s[a] is not None else 0.0
+        equad = float(equad) if np.ndim(equad) == 0 else equad
+        vecs.append(_wn_vectors(p, efacs[a], equad, flagid, flagl[a]))
+    z = _legacy_normals(seeds, [[n, n] for n in counts])
+    sigma = np.concatenate([errors_seconds(p.toas) for p in psrs])
+    ntot = int(np.sum(counts))
+    sig_d, ef_d, eq_d, z1_d, z2_d = dv.upload_packed([sigma, np.concatenate([v[0] for v in vecs]), np.concatenate([v[1] for v in vecs]),
+                                                      np.concatenate([x[0] for x in z]), np.concatenate([x[1] for x in z])])
+    out = dv.empty((1, ntot))
+    _lib.call("pta_wn", dv.ptr(sig_d), dv.ptr(ef_d), dv.ptr(eq_d), ntot, 1 if tnequad else 0, dv.ptr(z1_d), dv.ptr(z2_d),
+              ntot, 1, dv.ptr(out), ntot, 0, dv.stream_ptr())
+    res = np.split(dv.download(out[0]), np.cumsum(counts)[:-1])
+    for a, p in enumerate(psrs):
+        _record_wn(p, efacs[a], l10s[a], flagl[a], equad_str, res[a] * u.s)
+
+
+def _ecorr_vector(psr, ecorr, flagid, flags, first):
+    """per-epoch ECORR of one pulsar with the reference's checks (white_noise.py:166-180)."""
     ne = len(first)
     ecorrvec = np.zeros(ne)
     if flags is None:
@@ -111,19 +227,14 @@ def add_jitter(psr, log10_ecorr, flagid="f", flags=None, coarsegrain=0.1, seed=N
         ecorrvec = np.ones(ne) * ecorr
     if flags is not None and not np.isscalar(ecorr):
         if len(ecorr) == len(flags):
-            aveflags = np.array([f[flagid] for f in psr.toas.table["flags"].data])[first]  # first TOA labels the epoch (:35)
-            for ct, flag in enumerate(flags):
-                ecorrvec[flag == aveflags] = ecorr[ct]
+            labels, codes = flag_codes(psr.toas, flagid)
+            ecorrvec = _per_flag_vector(labels, codes[first], flags, ecorr)   # first TOA labels the epoch (:35)
         else:
             raise ValueError("ERROR: flags must be same length as jitter")
+    return ecorrvec
 
-    z = np.random.randn(ne)
-    n = len(times)
-    ep_d, ec_d, z_d = dv.i32(epoch_of), dv.f64(ecorrvec), dv.f64(z)
-    out = dv.empty((1, n))
-    _lib.call("pta_ecorr", dv.ptr(ep_d), dv.ptr(ec_d), n, ne, dv.ptr(z_d), ne, 1, dv.ptr(out), n, 0, dv.stream_ptr())
-    dt = u.s * out[0].cpu().numpy()
 
+def _record_jitter(psr, log10_ecorr, flags, dt):
     if flags is None:
         psr.update_added_signals("{}_jitter".format(psr.name), {"log10_ecorr": log10_ecorr}, dt)
     else:
@@ -132,6 +243,58 @@ def add_jitter(psr, log10_ecorr, flagid="f", flags=None, coarsegrain=0.1, seed=N
             psr.update_added_signals("{}_{}_jitter".format(psr.name, flag), {"log10_ecorr": log10_ecorr[i]})
     psr.toas.adjust_TOAs(TimeDelta(dt.to("day")))
     psr.update_residuals()
+
+
+def add_jitter(psr, log10_ecorr, flagid="f", flags=None, coarsegrain=0.1, seed=None):
+    """Add correlated (ECORR) noise of rms ecorr [s] per epoch, epochs = greedy buckets of width ``coarsegrain``
+    days (white_noise.py:128-198).  ``psr`` may be a LIST of pulsars (per-pulsar ``log10_ecorr`` / ``flags`` / ``seed`` lists)."""
+    if isinstance(psr, (list, tuple)):
+        return _add_jitter_list(list(psr), log10_ecorr, flagid, flags, coarsegrain, seed)
+    ecorr = 10 ** log10_ecorr
+    if seed is not None:
+        np.random.seed(seed)
+    times = np.asarray(psr.toas.get_mjds().value, dtype=np.float64)
+    epoch_of, first = epoch_map(times, coarsegrain)
+    ne = len(first)
+    ecorrvec = _ecorr_vector(psr, ecorr, flagid, flags, first)
+    z = np.random.randn(ne)
+    n = len(times)
+    ep_d, ec_d, z_d = dv.upload_packed([epoch_of, ecorrvec, z])
+    out = dv.empty((1, n))
+    _lib.call("pta_ecorr", dv.ptr(ep_d), dv.ptr(ec_d), n, ne, dv.ptr(z_d), ne, 1, dv.ptr(out), n, 0, dv.stream_ptr())
+    dt = u.s * dv.download(out[0])
+    _record_jitter(psr, log10_ecorr, flags, dt)
+
+
+def _add_jitter_list(psrs, log10_ecorr, flagid, flags, coarsegrain, seed):
+    P = len(psrs)
+    l10s = _broadcast(log10_ecorr, P, "log10_ecorr")
+    if flags is not None and len(flags) != P:
+        raise ValueError("flags must be a per-pulsar list of flag lists")
+    flagl = flags if flags is not None else [None] * P
+    seeds = None if seed is None else list(seed)
+    if seeds is not None and len(seeds) != P:
+        raise ValueError("seed must be None or one seed per pulsar")
+    eps, vecs, nes = [], [], []
+    for a, p in enumerate(psrs):
+        times = np.asarray(p.toas.get_mjds().value, dtype=np.float64)
+        epoch_of, first = epoch_map(times, coarsegrain)
+        ecorr = 10 ** np.asarray(l10s[a], dtype=float)
+        ecorr = float(ecorr) if np.ndim(ecorr) == 0 else ecorr
+        vecs.append(_ecorr_vector(p, ecorr, flagid, flagl[a], first))
+        eps.append(epoch_of)
+        nes.append(len(first))
+    z = _legacy_normals(seeds, [[ne] for ne in nes])
+    eoff = np.concatenate([[0], np.cumsum(nes)]).astype(np.int64)
+    counts = [len(e) for e in eps]
+    ntot, etot = int(np.sum(counts)), int(eoff[-1])
+    ep_all = np.concatenate([e.astype(np.int64) + eoff[a] for a, e in enumerate(eps)]).astype(np.int32)
+    ep_d, ec_d, z_d = dv.upload_packed([ep_all, np.concatenate(vecs), np.concatenate([x[0] for x in z])])
+    out = dv.empty((1, ntot))
+    _lib.call("pta_ecorr", dv.ptr(ep_d), dv.ptr(ec_d), ntot, etot, dv.ptr(z_d), etot, 1, dv.ptr(out), ntot, 0, dv.stream_ptr())
+    res = np.split(dv.download(out[0]), np.cumsum(counts)[:-1])
+    for a, p in enumerate(psrs):
+        _record_jitter(p, l10s[a], flagl[a], u.s * res[a])
 
 
 def add_efac(psr, efac=1.0, flagid="f", flags=None, seed=None):
