@@ -389,6 +389,18 @@ typedef struct {
 
 int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out, void *stream);
 
+/* ---------------------------------------------------------------- multi-GPU -------- */
+/* The path's one collective (BASELINE.json north_star: "RCCL over xGMI only to all-gather the final residual arrays
+ * back to rank 0"): realisations are sharded by contiguous row ranges - rank r owns rows [a_r, b_r) of the [total_rows x n_cols]
+ * ensemble, sizes differing by at most one (a_r = r * (total / world) + min(r, total % world)) - and rank `dst` receives every
+ * shard directly into its rows of `out` (point-to-point ncclRecv into row slices inside one group: no staging buffers, no
+ * concatenation).  `comm` is the caller's ncclComm_t (RCCL); `local` this rank's shard [b_r - a_r, n_cols], `out` (on `dst` only)
+ * the [total_rows, n_cols] result.  Asynchronous on `stream`.  world == 1: a device-to-device copy, no communicator needed.  RCCL is
+ * bound at run time from the copy already loaded into the process (PyTorch's), so the library has no link-time dependency on it.
+ * The reference has no counterpart (single process).                                                              */
+int pta_gather_rank0(void *comm, int rank, int world, int dst, const double *local, int64_t total_rows, int64_t n_cols,
+                     int64_t ld_local, double *out, int64_t ld_out, void *stream);
+
 /* ---------------------------------------------------------------- fp64 GEMM -------- */
 /* C[b] = alpha * A[b] * op(B[b]) + beta * C[b], row-major, batch `batch` with element strides.
  * A element (m,k) = A[m*lda + k*ska] (ska = 2 reads the real or imaginary plane of interleaved

@@ -9,6 +9,9 @@ north_star.  Rank 0's ingress (7 xGMI links) bounds it - 39 GB at config 4, >= 3
 rank 0 receives each chunk STRAIGHT into its rows of the final [total, n_toa] tensor (point-to-point receives into
 row slices: no per-rank staging buffers, no concatenation - rank 0 holds the ensemble once).
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -164,3 +167,75 @@ def gather_to_rank0(local, total=None, dst=0):
     for req in reqs:
         req.wait()
     return result
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the same gather through the C ABI (pta_gather_rank0): for integrators that bind the library with ctypes and do not want
+# torch.distributed on the data path.  The communicator is a plain ncclComm_t created on the librccl.so PyTorch ships.
+# ---------------------------------------------------------------------------------------------------------------------------
+class RcclComm:
+    """An RCCL communicator (ncclComm_t) created through ctypes.  ``unique_id()`` on one rank, hand the 128 bytes to the others by
+    any channel (``from_process_group`` uses torch.distributed's object broadcast), then ``RcclComm(rank, world, uid)`` on every
+    rank with its GPU current."""
+
+    class _Uid(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    @staticmethod
+    def _lib():
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return ctypes.CDLL(path if os.path.exists(path) else "librccl.so")
+
+    @classmethod
+    def unique_id(cls):
+        uid = cls._Uid()
+        rc = cls._lib().ncclGetUniqueId(ctypes.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
+        return ctypes.string_at(ctypes.addressof(uid), 128)
+
+    def __init__(self, rank, world, uid_bytes):
+        self.rank, self.world = int(rank), int(world)
+        self._rccl = self._lib()
+        uid = self._Uid()
+        ctypes.memmove(ctypes.addressof(uid), uid_bytes, 128)
+        self._comm = ctypes.c_void_p()
+        self._rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._Uid, ctypes.c_int]
+        rc = self._rccl.ncclCommInitRank(ctypes.byref(self._comm), self.world, uid, self.rank)
+        if rc != 0:
+            raise RuntimeError(f"ncclCommInitRank failed ({rc})")
+
+    @classmethod
+    def from_process_group(cls):
+        """one communicator per rank of the initialised torch.distributed job (the unique id travels by broadcast_object_list)."""
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+        box = [cls.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return cls(rank, world, box[0])
+
+    @property
+    def ptr(self):
+        return self._comm
+
+    def destroy(self):
+        if self._comm:
+            self._rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self._rccl.ncclCommDestroy(self._comm)
+            self._comm = None
+
+
+def gather_to_rank0_abi(local, total, comm=None, dst=0):
+    """gather_to_rank0 through pta_gather_rank0 (include/pta_replicator_amd.h): ``local`` is this rank's [shard, n] float64 device
+    tensor in shard_range() layout; returns the [total, n] tensor on ``dst``, None elsewhere.  ``comm``: an RcclComm (not needed for a
+    single rank)."""
+    from . import _lib, device as dv
+    rank, world = (comm.rank, comm.world) if comm is not None else (0, 1)
+    a, b = shard_range(total, rank, world)
+    assert local.shape[0] == b - a and local.dtype == torch.float64
+    local = local.contiguous()
+    n = int(local.shape[1])
+    out = torch.empty((total, n), dtype=torch.float64, device=local.device) if rank == dst else None
+    _lib.call("pta_gather_rank0", comm.ptr if comm is not None else None, rank, world, dst, dv.ptr(local) if b > a else None, int(total), n, n,
+              dv.ptr(out) if out is not None else None, n, dv.stream_ptr())
+    return out

@@ -1,0 +1,66 @@
+"""Multi-GPU tests (run with -m gpu): skipped on boxes with fewer GPUs than ranks - the development box and the driver's 1-GPU lease
+have one - so that the first multi-GPU node that runs the suite exercises the RCCL point-to-point schedule of
+pta_replicator_amd.distributed on hardware.  The multi-rank control flow is covered on CPU by
+tests/test_distributed_gloo.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,total", [(2, 37), (8, 37), (8, 5)])     # ragged shards; (8, 5): three ranks own no realisation
+def test_rccl_ranks_reproduce_the_single_gpu_ensemble(world, total, tmp_path):
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    from bench import configure_engine, headline_array
+    from pta_replicator_amd.engine import ReplicaEngine
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "multi_gpu_worker.py"), str(tmp_path), str(total)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    z = np.load(tmp_path / "rank0.npz")
+    assert int(z["ranks_seen"]) == world
+    psrs, noise = headline_array(5, 700)
+    eng = configure_engine(ReplicaEngine(psrs, seed=31), noise).prepare()
+    ref = eng.generate(total, r0=3).cpu().numpy()
+    for k in ("a", "b", "c"):                      # plain gather, pipelined generate + gather, C-ABI gather: bit-identical
+        assert np.array_equal(z[k], ref), k
+    eng.prepare_td()
+    assert np.array_equal(z["d"], eng.generate_td(total, r0=3).cpu().numpy())
+
+
+def test_c_abi_gather_single_rank_and_rccl_communicator():
+    """pta_gather_rank0 with one rank (a strided device copy, no communicator) and a real one-rank ncclComm_t created through ctypes on
+    PyTorch's librccl.so - what a ctypes-only integrator would do."""
+    import torch
+    from pta_replicator_amd import _lib, device as dv
+    from pta_replicator_amd.distributed import RcclComm, gather_to_rank0_abi
+    x = torch.randn((7, 33), dtype=torch.float64, device="cuda")
+    assert torch.equal(gather_to_rank0_abi(x, 7), x)
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    try:
+        assert comm.ptr.value
+        assert torch.equal(gather_to_rank0_abi(x, 7, comm), x)
+        # leading dimensions on a single rank
+        big = torch.zeros((7, 40), dtype=torch.float64, device="cuda")
+        _lib.call("pta_gather_rank0", comm.ptr, 0, 1, 0, dv.ptr(x), 7, 33, 33, dv.ptr(big), 40, dv.stream_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(big[:, :33], x) and float(big[:, 33:].abs().sum()) == 0.0
+    finally:
+        comm.destroy()
+    with pytest.raises(_lib.PtaError):
+        _lib.call("pta_gather_rank0", None, 0, 2, 0, dv.ptr(x), 14, 33, 33, dv.ptr(x), 33, dv.stream_ptr())   # two ranks need a communicator
