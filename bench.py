@@ -249,8 +249,17 @@ def td_mode_numbers(eng, R):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps
 
-    t_first = wall(eng.prepare_td)
+    # what a first prepare_td() costs beyond its kernels is the driver allocating the factor buffer (13.6 GB at 68 x 5000: hipMalloc of
+    # fresh memory, ~0.2-0.4 s, paid once per process - the caching allocator hands the block back on later calls): timed on its own,
+    # then prepare_td() twice - the first call still creates the internal streams / events and the GWB grid factor
     counts = [int(c) for c in eng.counts]
+    nbytes = 8 * sum(n * (n + (n & 1)) for n in counts)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    blk = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize(); t_alloc = time.perf_counter() - t0
+    del blk
+    t_first = wall(eng.prepare_td)
+    t_warm = wall(eng.prepare_td)
     s = dv.stream_ptr()
     phi = (eng.d_amp ** 2).contiguous()
     ec2 = (eng.d_ecorr_toa ** 2).contiguous()
@@ -260,7 +269,8 @@ def td_mode_numbers(eng, R):
                   dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), s)
 
     uniform = len(set(counts)) == 1
-    res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_first * 1e3}
+    res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_warm * 1e3, "prepare_td_first_call_ms": t_first * 1e3,
+           "factor_buffer_alloc_ms": t_alloc * 1e3, "factor_buffer_GB": nbytes / 1e9}
     flop_chol = sum(n ** 3 for n in counts) / 3.0
     if uniform:
         n, ld, P = counts[0], eng.td_ld[0], eng.P
@@ -360,6 +370,11 @@ def main():
     eng.gwb_mode = "grid"
     elapsed_grid = timed_steps()
     eng.gwb_mode = "fourier"
+    # (iii) EFAC / EQUAD drawn with ONE deviate per TOA of the combined amplitude sqrt((efac sigma)^2 + (efac equad)^2) instead of the
+    # reference's two (white_noise.py:105-109): same distribution, half the Box-Muller pairs of the fused kernel, not replayable
+    eng.wn_mode = "single"
+    elapsed_single = timed_steps()
+    eng.wn_mode = "reference"
 
     # ---- N > 1: what the ranks actually did - an all_reduce of ones over RCCL (ranks seen), every rank's own
     # ms_per_step (all_gather), and BASELINE.json config 4's shape: 2048 realisations per GPU of the same array + one CGW ----
@@ -590,6 +605,7 @@ def main():
                    "realisations_per_step_per_gpu": R, "n_toa_total": eng.n_toa, "Nf": Nf, "npts": npts, "parallelism": f"replica-shard x{world}"},
         "value_fast_rng_math": world * R * K / elapsed_fast,
         "value_gwb_grid_draws": world * R * K / elapsed_grid,
+        "value_single_deviate_wn": world * R * K / elapsed_single,
         "roofline": roof, "step": step_block, "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "microbench": micro,
     }
     if world > 1:

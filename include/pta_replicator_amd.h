@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 2
+#define PTA_ABI_VERSION 3
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -290,6 +290,9 @@ typedef struct {
   const int32_t *epoch_of;    /* [n_toa] epoch index inside the pulsar */
   const double *ecorr_toa;    /* [n_toa] ecorr of the TOA's epoch (0 = none) */
   const double *det;          /* [n_toa] realisation-independent deterministic delay (e.g. CGW) */
+  const double *wn_c;         /* opt-in, INSTEAD of wn_a / wn_b (ABI 3): [n_toa] sqrt(wn_a^2 + wn_b^2) - ONE deviate per TOA with the
+                                 combined EFAC/EQUAD amplitude (same distribution as white_noise.py:105-109, half the Box-Muller pairs;
+                                 not the reference's draw order: TOA idx takes branch (idx >> 4) & 1 of pair idx & ~16 of stream (WN, a)) */
   int32_t rng_fast;           /* Gaussian transform of the on-chip draws (see "RNG" above); 0 = fp64 (default) */
   int32_t synth_variant;      /* fused-kernel variant: 0 (default) = red-noise F @ y on the matrix cores (16 realisations x 256 TOAs
                                  per workgroup), workgroups dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same

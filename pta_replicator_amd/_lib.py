@@ -37,7 +37,7 @@ class EnginePlan(ctypes.Structure):
         ("tile_psr", _P), ("tile_start", _P), ("tile_count", _P), ("tile_ep0", _P), ("tile_epn", _P),
         ("idx_in_psr", _P), ("Ft", _P), ("ldf", c_int64), ("rn_coef", _P), ("gw_G", _P),
         ("gw_jlo", _P), ("gw_w", _P), ("wn_a", _P), ("wn_b", _P), ("epoch_of", _P),
-        ("ecorr_toa", _P), ("det", _P), ("rng_fast", c_int32), ("synth_variant", c_int32),
+        ("ecorr_toa", _P), ("det", _P), ("wn_c", _P), ("rng_fast", c_int32), ("synth_variant", c_int32),
     ]
 
 
@@ -131,7 +131,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.pta_abi_version() != 2:
+if lib.pta_abi_version() != 3:
     raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
 
 

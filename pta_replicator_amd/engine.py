@@ -73,6 +73,11 @@ class ReplicaEngine(TimeDomainMixin):
         # per pulsar through the Cholesky factor of the covariance that synthesis implies on the npts-sample grid (SURVEY.md
         # App. A.1) - same distribution, 10x fewer deviates, the transform becomes an MFMA triangular product
         self.gwb_mode = "fourier"
+        # how the EFAC/EQUAD term of generate() is drawn: "reference" (default) = two deviates per TOA, (efac sigma) z1 + (efac equad) z2,
+        # the reference's own draws (white_noise.py:105-109: replayable, dump_draws / replay); "single" = ONE deviate per TOA with the
+        # combined amplitude sqrt((efac sigma)^2 + (efac equad | equad)^2) - same distribution, half the Box-Muller pairs of the fused
+        # kernel, not the reference's draw order (opt-in secondary number of bench.py, never `value`)
+        self.wn_mode = "reference"
         self.workspace_bytes = 8 << 30   # upper bound of the per-batch workspace of generate() (cap by bytes, not only by count)
 
     # ---------------------------------------------------------------- configuration -------------
@@ -168,7 +173,7 @@ class ReplicaEngine(TimeDomainMixin):
             pl.rn_k, pl.Ft, pl.ldf = K, self.d_Ft.data_ptr(), N
 
         # ---- EFAC / EQUAD vectors
-        pl.wn_a = pl.wn_b = None
+        pl.wn_a = pl.wn_b = pl.wn_c = None
         if self._wn is not None:
             c = self._wn
             wa, wb = np.zeros(N), np.zeros(N)
@@ -196,7 +201,7 @@ class ReplicaEngine(TimeDomainMixin):
                 sl = slice(self.off[a], self.off[a + 1])
                 wa[sl] = ev * self.sigma_s[a]
                 wb[sl] = qv if c["tnequad"] else ev * qv
-            self.d_wn_a, self.d_wn_b = dv.f64(wa), dv.f64(wb)
+            self.d_wn_a, self.d_wn_b, self.d_wn_c = dv.f64(wa), dv.f64(wb), dv.f64(np.hypot(wa, wb))
             pl.wn_a, pl.wn_b, pl.tnequad = self.d_wn_a.data_ptr(), self.d_wn_b.data_ptr(), int(c["tnequad"])
 
         # ---- ECORR epoch maps
@@ -392,9 +397,9 @@ class ReplicaEngine(TimeDomainMixin):
             n = min(step, R - lo)
             optr = ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0))
             if not grid_mode:
-                _lib.call("pta_engine_generate", ctypes.byref(self.plan), ctypes.byref(ws["tables"]), self.seed, r0 + lo, n, optr, out.stride(0), s)
+                _lib.call("pta_engine_generate", ctypes.byref(self._plan_for_mode()), ctypes.byref(ws["tables"]), self.seed, r0 + lo, n, optr, out.stride(0), s)
                 continue
-            pl = _lib.EnginePlan.from_buffer_copy(self.plan)
+            pl = _lib.EnginePlan.from_buffer_copy(self._plan_for_mode())
             if pl.rn_k:
                 _lib.call("pta_engine_rn_coef", self.seed, r0 + lo, n, self.P, self.K, dv.ptr(self.d_amp), dv.ptr(ws["coef"]), int(self.rng_fast), s)
                 pl.rn_coef = ws["coef"].data_ptr()
@@ -407,6 +412,32 @@ class ReplicaEngine(TimeDomainMixin):
             self.plan.rn_coef = ws["coef"].data_ptr()
         if self.plan.gw_npts:
             self.plan.gw_G = ws["G"].data_ptr()
+        return out
+
+    def _plan_for_mode(self):
+        """the plan generate() launches with: the shared one, or - wn_mode "single" - a private copy whose white-noise operands are
+        replaced by the combined amplitude vector (pta_engine_plan.wn_c)."""
+        if self.wn_mode == "reference" or not self.plan.wn_a:
+            return self.plan
+        if self.wn_mode != "single":
+            raise ValueError(f"wn_mode={self.wn_mode!r} must be 'reference' or 'single'")
+        pl = _lib.EnginePlan.from_buffer_copy(self.plan)
+        pl.wn_a = pl.wn_b = None
+        pl.wn_c = self.d_wn_c.data_ptr()
+        return pl
+
+    def dump_draws_wn_single(self, r):
+        """the ONE deviate per TOA realisation r uses in wn_mode "single": TOA idx of pulsar a takes branch (idx >> 4) & 1 of pair
+        idx & ~16 of stream (WN, a) - one array per pulsar."""
+        s = dv.stream_ptr()
+        out = []
+        for a in range(self.P):
+            n = int(self.counts[a])
+            z0, z1 = dv.empty((n,)), dv.empty((n,))
+            _lib.call("pta_rng_fill_normal", self.seed, r, 1, stream_id(STREAM_WN, a), n, 0, dv.ptr(z0), dv.ptr(z1), n, int(self.rng_fast), s)
+            idx = np.arange(n)
+            z0, z1 = z0.cpu().numpy(), z1.cpu().numpy()
+            out.append(np.where((idx >> 4) & 1, z1[idx & ~16], z0[idx & ~16]))
         return out
 
     def generate_per_signal(self, R, r0=0):

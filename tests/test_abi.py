@@ -27,7 +27,7 @@ def test_header_declares_the_expected_surface():
                  "pta_cgw", "pta_engine_synth", "pta_td_cov_assemble", "pta_td_trmm", "pta_td_trmm_rng", "pta_potrf_batched_ex", "pta_dgemm",
                  "pta_rng_fill_normal"):
         assert name in d, name
-    assert not [n for n in d if n.startswith("pta_set_")], "ABI 2 has no process-wide switches"
+    assert not [n for n in d if n.startswith("pta_set_")], "the ABI has no process-wide switches"
 
 
 def test_library_exports_every_declared_symbol():
@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_error_channel_without_gpu():
     from pta_replicator_amd import _lib
-    assert _lib.lib.pta_abi_version() == 2
+    assert _lib.lib.pta_abi_version() == 3
     rc = _lib.lib.pta_quantize_epochs(None, 0, 1.0, None, None, None, None)
     assert rc == -1 and "NULL" in _lib.last_error()
     with pytest.raises(_lib.PtaError):
