@@ -95,37 +95,58 @@ extern "C" int pta_td_cov_assemble(const double *Ft, int64_t ldf, int N, int K, 
 // are rows of the K-major design matrix (coalesced, conflict-free LDS stores: 16 lanes write 16 consecutive doubles).
 #define TC_T 128
 #define TC_LD 144  // == 16 (mod 32)
-__global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
+// TM = rows of the output tile: 128 (round 2) or 64.  The kernel is a short product (K = 60: four slabs) in front of a long
+// epilogue (epoch / variance vectors, LDS staging, 64-128 KB of stores that must be acknowledged before the workgroup retires), so
+// what it needs is workgroups in DIFFERENT phases on a CU: the 64-row tile halves the accumulators (64 instead of 128 VGPRs) and the
+// operand slabs, which lets a third workgroup in - one's stores drain under the others' MFMAs.
+template <int TM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ? 2 : 3, TM == 128 ? 2 : 3))) void k_td_cov128(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
                                                       const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
                                                       const double *__restrict__ ecorr2, double *__restrict__ Cbase,
                                                       const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
                                                       const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off) {
+  constexpr int TMI = TM / 32;          // 16-row MFMA tiles per wave (waves as 2 x 2: each TM / 2 rows x 64 columns)
+  constexpr int ALD = TM + 16;          // A slab pitch (doubles), == 16 (mod 32)
+  constexpr int NBUF = TM == 128 ? 2 : 1;  // 64-row tiles: single-buffered slabs (34 KB of LDS with the staging tile: the third workgroup
+                                           // must fit beside the other two's 160 KB; its extra barrier per slab is what they overlap)
   const int blk = blockIdx.y;
   const int N = blk_n[blk];
   const int tix = blockIdx.x;
-  int bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-  while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
-  while (bm * (bm + 1) / 2 > tix) --bm;
-  const int bn = tix - bm * (bm + 1) / 2;
-  const int m0 = bm * TC_T, n0 = bn * TC_T;
+  int bm, bn;
+  if (TM == 128) {  // lower-triangular tiles, row by row: tix = bm (bm + 1) / 2 + bn
+    bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+    while (bm * (bm + 1) / 2 > tix) --bm;
+    bn = tix - bm * (bm + 1) / 2;
+  } else {          // 64-row blocks 2 p and 2 p + 1 both meet column tiles 0 .. p: tix = p (p + 1) + r, r < 2 (p + 1)
+    int p = (int)((sqrt(4.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while ((p + 1) * (p + 2) <= tix) ++p;
+    while (p * (p + 1) > tix) --p;
+    const int r = tix - p * (p + 1);
+    bm = 2 * p + (r > p ? 1 : 0);
+    bn = r > p ? r - (p + 1) : r;
+  }
+  const int m0 = bm * TM, n0 = bn * TC_T;
   if (m0 >= N) return;  // a block smaller than the largest one
   const int64_t off = blk_off[blk];
   const int64_t ldc = blk_ld[blk];
   double *__restrict__ C = Cbase + blk_pos[blk];
   const double *__restrict__ F = Ft + off;
   const double *__restrict__ ph = phi ? phi + (int64_t)blk * K : nullptr;
-  __shared__ double smem[4 * TBK * TC_LD];  // operand slabs As[2][16][144], Bs[2][16][144]; reused as the output staging tile
-  double (*As)[TBK][TC_LD] = reinterpret_cast<double (*)[TBK][TC_LD]>(smem);
-  double (*Bs)[TBK][TC_LD] = reinterpret_cast<double (*)[TBK][TC_LD]>(smem + 2 * TBK * TC_LD);
+  // operand slabs As[2][16][ALD], Bs[2][16][144]; reused as the output staging tile [TM / 2][132]
+  constexpr int SLABS = NBUF * TBK * ALD + NBUF * TBK * TC_LD, STAGE = (TM / 2) * (TC_T + 4);
+  __shared__ double smem[SLABS > STAGE ? SLABS : STAGE];
+  double (*As)[TBK][ALD] = reinterpret_cast<double (*)[TBK][ALD]>(smem);
+  double (*Bs)[TBK][TC_LD] = reinterpret_cast<double (*)[TBK][TC_LD]>(smem + NBUF * TBK * ALD);
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
-  pta_f64x4 acc[4][4];
+  pta_f64x4 acc[TMI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
   const int kr = t >> 4, cq = t & 15;  // slab row (k) and column phase of this thread; columns cq + 16 j
-  double ra[8], rb[8];
+  double ra[TM / 16], rb[8];
   // every load unconditional, from a clamped (always valid) address: a bin beyond K enters with phi = 0, a row / column beyond N
   // lands in a part of the tile that is never stored.  (Predicated, each of the 17 loads of a slab sat in its own exec-masked
   // block behind an s_waitcnt vmcnt(0): 17 serialised L2 round trips per slab.)
@@ -138,18 +159,16 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
     pk_in = gk < K;
     const double *__restrict__ Fk = F + (int64_t)gkc * ldf;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ra[j] = Fk[min(m0 + cq + 16 * j, N - 1)];
-      rb[j] = Fk[min(n0 + cq + 16 * j, N - 1)];
-    }
+    for (int j = 0; j < TM / 16; ++j) ra[j] = Fk[min(m0 + cq + 16 * j, N - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rb[j] = Fk[min(n0 + cq + 16 * j, N - 1)];
   };
   auto stash = [&](int buf) {
     const double p = pk_in ? pk : 0.0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      As[buf][kr][cq + 16 * j] = p * ra[j];
-      Bs[buf][kr][cq + 16 * j] = rb[j];
-    }
+    for (int j = 0; j < TM / 16; ++j) As[buf][kr][cq + 16 * j] = p * ra[j];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Bs[buf][kr][cq + 16 * j] = rb[j];
   };
   const int nslab = (K + TBK - 1) / TBK;
   if (nslab > 0) {
@@ -158,32 +177,33 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
   }
   __syncthreads();
   for (int sidx = 0; sidx < nslab; ++sidx) {
-    const int cur = sidx & 1;
+    const int cur = NBUF == 2 ? (sidx & 1) : 0;
     if (sidx + 1 < nslab) fetch((sidx + 1) * TBK);
 #pragma unroll
     for (int kk = 0; kk < TBK; kk += 4) {
-      double a[4], b[4];
+      double a[TMI], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[cur][kk + (l >> 4)][wm * 64 + i * 16 + (l & 15)];
+      for (int i = 0; i < TMI; ++i) a[i] = As[cur][kk + (l >> 4)][wm * (TM / 2) + i * 16 + (l & 15)];
 #pragma unroll
       for (int j = 0; j < 4; ++j) b[j] = Bs[cur][kk + (l >> 4)][wn * 64 + j * 16 + (l & 15)];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TMI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = pta_mfma_f64(a[i], b[j], acc[i][j]);
     }
-    if (sidx + 1 < nslab) stash(cur ^ 1);
+    if (NBUF == 1) __syncthreads();  // every wave has read the slab before it is replaced
+    if (sidx + 1 < nslab) stash(NBUF == 2 ? (cur ^ 1) : 0);
     __syncthreads();
   }
-  // epilogue.  The white and ECORR terms are added in registers (the epochs of the 16 rows and 4 columns a lane owns are read
+  // epilogue.  The white and ECORR terms are added in registers (the epochs of the rows and 4 columns a lane owns are read
   // once); the tile then goes through LDS so that every store instruction of a wave writes ONE whole 1 KB row segment (64 lanes
   // x 16 bytes) instead of four 128-byte pieces of four different rows: DRAM pages are opened once per row, not per piece.
-  int erow[4][4], ecol[4];
+  int erow[TMI][4], ecol[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TMI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
+      const int row = m0 + wm * (TM / 2) + i * 16 + pta_mfma_row(l, r);
       erow[i][r] = (epoch_of && row < N) ? epoch_of[off + row] : -2;
     }
 #pragma unroll
@@ -191,22 +211,19 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
     const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
     ecol[j] = (epoch_of && col < N) ? epoch_of[off + col] : -1;
   }
-  // the diagonal (white) term exists only in diagonal tiles and the ECORR block only where an epoch of the rows meets the same
-  // epoch among the columns; both vectors are read for all 16 rows of the lane in one go (clamped addresses), then added by
-  // selects - no load sits behind a per-element predicate
-  const bool diag_tile = (bm == bn);  // workgroup-uniform
+  const bool diag_tile = n0 <= m0 + TM - 1 && n0 + TC_T - 1 >= m0;  // workgroup-uniform
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < TMI; ++i) {
     double s2[4], e2[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int rowc = min(m0 + wm * 64 + i * 16 + pta_mfma_row(l, r), N - 1);
+      const int rowc = min(m0 + wm * (TM / 2) + i * 16 + pta_mfma_row(l, r), N - 1);
       s2[r] = diag_tile ? sigma2[off + rowc] : 0.0;
       e2[r] = epoch_of ? ecorr2[off + rowc] : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 64 + i * 16 + pta_mfma_row(l, r);
+      const int row = m0 + wm * (TM / 2) + i * 16 + pta_mfma_row(l, r);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + pta_mfma_col(l);
@@ -216,21 +233,21 @@ __global__ __launch_bounds__(256, 2) void k_td_cov128(const double *__restrict__
       }
     }
   }
-  constexpr int SLD = TC_T + 4;                      // staging pitch (doubles): 64 x 132 x 8 B = 67.6 KB <= the 73.7 KB of slabs
+  constexpr int SLD = TC_T + 4;                      // staging pitch (doubles): [TM / 2][132] fits inside the slabs
   double (*S)[SLD] = reinterpret_cast<double (*)[SLD]>(smem);
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     if (wm == half) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TMI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) S[i * 16 + pta_mfma_row(l, r)][wn * 64 + j * 16 + pta_mfma_col(l)] = acc[i][j][r];
     }
     __syncthreads();
-    for (int rr = w; rr < 64; rr += 4) {             // wave w stores rows w, w + 4, ... of this half; lane l columns 2l, 2l + 1
-      const int row = m0 + half * 64 + rr;
+    for (int rr = w; rr < TM / 2; rr += 4) {         // wave w stores rows w, w + 4, ... of this half; lane l columns 2l, 2l + 1
+      const int row = m0 + half * (TM / 2) + rr;
       if (row >= N) break;
       const int col = n0 + 2 * l;
       const double2 v = *reinterpret_cast<const double2 *>(&S[rr][2 * l]);
@@ -257,8 +274,10 @@ extern "C" int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, con
               n_blocks, max_n, K);
   PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_all: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
   const int64_t nt = pta_cdiv(max_n, TC_T);
-  PTA_REQUIRE(nt * (nt + 1) / 2 < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_all: max_n=%d too large", max_n);
-  hipLaunchKernelGGL(k_td_cov128, dim3((unsigned)(nt * (nt + 1) / 2), n_blocks), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,
+  PTA_REQUIRE(nt * (nt + 1) < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_all: max_n=%d too large", max_n);
+  // 64-row tiles (row blocks 2 p, 2 p + 1 x column tiles 0 .. p), three workgroups per CU: 2.97 ms for the 68 x 5000^2 lower triangles
+  // against 3.22 ms with round 2's 128-row tiles at two per CU (k_td_cov128<128>, same source)
+  hipLaunchKernelGGL(k_td_cov128<64>, dim3((unsigned)(nt * (nt + 1)), n_blocks), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,
                      epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
