@@ -392,6 +392,15 @@ typedef struct {
 
 int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out, void *stream);
 
+/* ---------------------------------------------------------------- host-sink replacement ---- */
+/* Linearised timing-model fit of a whole ensemble, in place:  rows[r, off_a + i]  <-  r - M_a (M_a^T W_a M_a)^-1 M_a^T W_a r  for every
+ * realisation r < R and pulsar a < P - what refitting the timing model after an injection removes from the residuals (the reference goes
+ * through PINT once per pulsar: simulate.py:40-69).  Mt[k*ld + i] = column k of the design matrices over the concatenated TOAs (k < m <= 12),
+ * Qt[k*ld + i] = row k of (M^T W M)^-1 M^T W (host, realisation independent), psr_off[P + 1] the pulsars' TOA offsets (device int32).
+ * One workgroup = one pulsar x 8 realisations; the m x 8 column reductions run as wavefront shuffles + one LDS exchange.          */
+int pta_tm_project(const double *Qt, const double *Mt, int64_t ld, int m, const int32_t *psr_off, int P, double *rows, int64_t ld_rows, int R,
+                   void *stream);
+
 /* ---------------------------------------------------------------- multi-GPU -------- */
 /* The path's one collective (BASELINE.json north_star: "RCCL over xGMI only to all-gather the final residual arrays
  * back to rank 0"): realisations are sharded by contiguous row ranges - rank r owns rows [a_r, b_r) of the [total_rows x n_cols]

@@ -638,16 +638,59 @@ class ReplicaEngine(TimeDomainMixin):
             psr.update_residuals()
         return row
 
-    def to_enterprise(self, rows, subtract_mean=True, timing_model="spin"):
+    # ---------------------------------------------------------------- timing-model projection ---
+    def prepare_timing_projection(self, model="spin"):
+        """Design matrices M_a (simulate.timing_design_matrix on the IDEAL TOAs: "spin" = offset, F0, F1; "astrometric" = + position,
+        proper motion, parallax) and the fit operators Q_a = (M^T W M)^-1 M^T W of every pulsar, W = 1 / sigma^2, on the device
+        (K-major over the concatenated TOAs, like Ft).  Realisation independent: computed once."""
+        from .simulate import timing_design_matrix
+        dv.require_gpu()
+        Mt = Qt = None
+        for a in range(self.P):
+            M, names = timing_design_matrix(self.mjd[a] * 86400.0, model=model)
+            w = 1.0 / self.sigma_s[a] ** 2
+            # scale the weights (the projection is invariant): sigma ~ 1e-6 s would put M^T W M at 1e12 and lose digits to nothing
+            w = w / w.mean()
+            A = M.T @ (M * w[:, None])
+            Q = np.linalg.solve(A, M.T * w[None, :])
+            if Mt is None:
+                m = M.shape[1]
+                Mt, Qt = np.zeros((m, self.n_toa)), np.zeros((m, self.n_toa))
+            Mt[:, self.off[a]:self.off[a + 1]] = M.T
+            Qt[:, self.off[a]:self.off[a + 1]] = Q
+        self._tm = dict(model=model, m=Mt.shape[0], names=names, Mt=dv.f64(Mt), Qt=dv.f64(Qt), off=dv.i32(self.off), Mt_host=Mt, Qt_host=Qt)
+        return self
+
+    def project_timing_model(self, rows, model="spin"):
+        """In place: every realisation of ``rows`` ([R, n_toa] device tensor, e.g. the output of generate()) loses what a linearised
+        refit of the pulsars' timing models would absorb, r <- r - M (M^T W M)^-1 M^T W r per (realisation, pulsar) - the batched
+        counterpart of the reference's fit + residual rebuild through PINT (simulate.py:40-69) for idealised timing models
+        (pta_tm_project, one launch).  The weighted-mean subtraction of PINT's default residuals is the one-column special case."""
+        if getattr(self, "_tm", None) is None or self._tm["model"] != model:
+            self.prepare_timing_projection(model)
+        tm = self._tm
+        assert rows.dim() == 2 and rows.shape[1] == self.n_toa and rows.stride(1) == 1
+        _lib.call("pta_tm_project", dv.ptr(tm["Qt"]), dv.ptr(tm["Mt"]), self.n_toa, tm["m"], dv.ptr(tm["off"]), self.P,
+                  ctypes.c_void_p(rows.data_ptr()), rows.stride(0), int(rows.shape[0]), dv.stream_ptr())
+        return rows
+
+    def to_enterprise(self, rows, subtract_mean=True, timing_model="spin", fitted=False):
         """enterprise-style pulsar objects for realisations already generated: ``rows`` is a [R, n_toa] tensor / array (e.g. the
         output of generate() or generate_td()); returns R lists of P ``ArrayEnterprisePulsar`` whose ``toas`` are the ideal TOAs
         shifted by the realisation's delay (what the reference's hand-off carries, simulate.py:91-95) and whose ``residuals`` are the
         injected delays with the weighted mean removed (what PINT's Residuals would report for an idealised pulsar, SURVEY.md §8
         a16) - the hand-off of SURVEY.md §8f rank 4 for whole ensembles, without a par/tim round trip.  Works for array-backed,
         PINT-backed and foreign pulsars alike: everything is read from the engine's own copies of the ideal TOAs / errors and the
-        pulsar's flag table."""
+        pulsar's flag table.  ``fitted=True``: the residuals are POST-FIT - the columns of ``Mmat`` are projected out of every
+        realisation on the device (project_timing_model) before the hand-off; the TOAs still carry the full injected delay."""
         from .simulate import ArrayEnterprisePulsar
         from ._position import ra_dec
+        if fitted:   # post-fit residuals: the design matrix handed over (Mmat) is projected out on the device, whole ensemble at once
+            dev = rows.detach().clone() if hasattr(rows, "detach") else dv.f64(np.atleast_2d(np.asarray(rows)))
+            if dev.dim() == 1:
+                dev = dev[None, :].contiguous()
+            rows = self.project_timing_model(dev, timing_model)
+            subtract_mean = False
         arr = rows.detach().cpu().numpy() if hasattr(rows, "detach") else np.asarray(rows)
         if arr.ndim == 1:
             arr = arr[None, :]
@@ -681,27 +724,28 @@ class ReplicaEngine(TimeDomainMixin):
     def write_tim_ensemble(self, rows, outdir, r0=0):
         """Batched counterpart of SimulatedPulsar.write_partim (simulate.py:71-77) for array-backed pulsars: one directory
         ``real_<r>/`` per realisation with a Tempo2 tim file per pulsar whose TOAs are the ideal TOAs shifted by the injected
-        delay - without touching the pulsar objects (no per-realisation adjust_TOAs / residual rebuild)."""
+        delay - without touching the pulsar objects (no per-realisation adjust_TOAs / residual rebuild) - and, ONCE (``par/``), the par
+        file of every pulsar: the timing models are the same in every realisation."""
         import os
-        from .simulate import ArrayTOAs
+        from .simulate import ArrayTOAs, minimal_par, write_tim
         arr = rows.detach().cpu().numpy() if hasattr(rows, "detach") else np.asarray(rows)
         if arr.ndim == 1:
             arr = arr[None, :]
+        for psr in self.psrs:
+            if not isinstance(psr.toas, ArrayTOAs):
+                raise NotImplementedError("write_tim_ensemble needs array-backed pulsars (PINT-backed: use inject() + write_partim)")
+        os.makedirs(os.path.join(outdir, "par"), exist_ok=True)
+        for psr in self.psrs:
+            with open(os.path.join(outdir, "par", f"{psr.name}.par"), "w") as fh:
+                fh.write(psr.par_text if getattr(psr, "par_text", None) else minimal_par(psr.name, psr.loc))
         paths = []
         for k, row in enumerate(arr):
             d = os.path.join(outdir, f"real_{r0 + k:06d}")
             os.makedirs(d, exist_ok=True)
             for a, psr in enumerate(self.psrs):
-                if not isinstance(psr.toas, ArrayTOAs):
-                    raise NotImplementedError("write_tim_ensemble needs array-backed pulsars (PINT-backed: use inject() + write_partim)")
                 mjd = psr.toas.mjd0_ld + (row[self.off[a]:self.off[a + 1]] / 86400.0).astype(np.longdouble)
                 path = os.path.join(d, f"{psr.name}.tim")
-                with open(path, "w") as fh:
-                    fh.write("FORMAT 1\n")
-                    for i in range(len(mjd)):
-                        fl = " ".join(f"-{kk} {v}" for kk, v in psr.toas.flags[i].items())
-                        fh.write(f" {psr.name} {psr.toas.freqs_mhz[i]:.8f} {np.format_float_positional(mjd[i], precision=19)} "
-                                 f"{psr.toas.errors_us[i]:.5f} AXIS {fl}\n")
+                write_tim(path, psr.name, mjd, psr.toas.errors_us, psr.toas.freqs_mhz, psr.toas.flags)
                 paths.append(path)
         return paths
 

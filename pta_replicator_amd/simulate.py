@@ -129,6 +129,7 @@ class SimulatedPulsar:
     loc: dict = None
     added_signals: dict = None
     added_signals_time: dict = None
+    par_text: str = None     # array-backed pulsars: the par file the pulsar was loaded from, verbatim (injection never changes the model)
 
     def __repr__(self):
         return f"SimulatedPulsar({self.name})"
@@ -159,14 +160,14 @@ class SimulatedPulsar:
         self.update_residuals()
 
     def write_partim(self, outpar, outtim, tempo2=False):
-        """Write par/tim (simulate.py:71-77).  Array-backed pulsars write a Tempo2 tim file only."""
+        """Write par/tim (simulate.py:71-77).  Array-backed pulsars: a Tempo2 tim file of the shifted TOAs, and the par file the pulsar
+        was loaded from, verbatim - injection shifts TOAs, it never touches the timing model (the reference writes its unchanged
+        ``model`` back out unless fit() was called).  A pulsar built in code has no par source: a minimal par with its name and
+        position is written, marked as such."""
         if isinstance(self.toas, ArrayTOAs):
-            with open(outtim, "w") as fh:
-                fh.write("FORMAT 1\n")
-                for i in range(self.toas.ntoas):
-                    fl = " ".join(f"-{k} {v}" for k, v in self.toas.flags[i].items())
-                    fh.write(f" {self.name} {self.toas.freqs_mhz[i]:.8f} {np.format_float_positional(self.toas.mjd_ld[i], precision=19)} "
-                             f"{self.toas.errors_us[i]:.5f} AXIS {fl}\n")
+            write_tim(outtim, self.name, self.toas.mjd_ld, self.toas.errors_us, self.toas.freqs_mhz, self.toas.flags)
+            with open(outpar, "w") as fh:
+                fh.write(self.par_text if self.par_text else minimal_par(self.name, self.loc))
             return
         self.model.write_parfile(outpar)
         self.toas.write_TOA_file(outtim, format="Tempo2") if tempo2 else self.toas.write_TOA_file(outtim)
@@ -318,6 +319,35 @@ def read_par_location(parfile):
     return name, loc
 
 
+def write_tim(path, name, mjd_ld, errors_us, freqs_mhz, flags):
+    """Tempo2 "FORMAT 1" tim file from arrays (19 decimals of MJD: sub-ns at longdouble precision)."""
+    with open(path, "w") as fh:
+        fh.write("FORMAT 1\n")
+        for i in range(len(mjd_ld)):
+            fl = " ".join(f"-{k} {v}" for k, v in flags[i].items())
+            fh.write(f" {name} {freqs_mhz[i]:.8f} {np.format_float_positional(mjd_ld[i], precision=19)} {errors_us[i]:.5f} AXIS {fl}\n")
+
+
+def _sexagesimal_str(value, sign=False):
+    s = "-" if value < 0 else ("+" if sign else "")
+    v = abs(float(value))
+    d = int(v)
+    m = int((v - d) * 60)
+    sec = (v - d - m / 60.0) * 3600.0
+    return f"{s}{d:02d}:{m:02d}:{sec:011.8f}"
+
+
+def minimal_par(name, loc):
+    """par text for a pulsar that was built in code (no par file to copy): name and position only, flagged as a stub - enough for
+    tools that read the sky position; not a timing solution."""
+    lines = ["# written by pta_replicator_amd for an array-backed pulsar without a par source: name and position only", f"PSR {name}"]
+    if loc and "RAJ" in loc and "DECJ" in loc:
+        lines += [f"RAJ {_sexagesimal_str(loc['RAJ'])}", f"DECJ {_sexagesimal_str(loc['DECJ'], sign=True)}"]
+    elif loc and "ELONG" in loc and "ELAT" in loc:
+        lines += [f"ELONG {float(loc['ELONG']):.12f}", f"ELAT {float(loc['ELAT']):.12f}"]
+    return "\n".join(lines) + "\n"
+
+
 def read_tim(timfile):
     """Tempo2-format tim file -> (mjd longdouble[N], error_us[N], freq_mhz[N], flags list[dict])."""
     if not os.path.isfile(timfile):
@@ -358,7 +388,9 @@ def simulate_pulsar(parfile, obstimes, toaerr, freq=1440.0, observatory="AXIS", 
     n = len(obstimes)
     fl = [dict(flags) for _ in range(n)] if isinstance(flags, dict) else flags
     toas = ArrayTOAs(obstimes, toaerr, fl, freq)
-    psr = SimulatedPulsar(ephem=ephem, model=None, toas=toas, name=name, loc=loc)
+    with open(parfile) as fh:
+        par_text = fh.read()
+    psr = SimulatedPulsar(ephem=ephem, model=None, toas=toas, name=name, loc=loc, par_text=par_text)
     psr.update_residuals()
     return psr
 
@@ -375,7 +407,9 @@ def load_pulsar(parfile, timfile, ephem="DE440"):
         toas = _pint_toa.get_TOAs(timfile, ephem=ephem, planets=True)
         return SimulatedPulsar(ephem=ephem, model=model, toas=toas, residuals=_PintResiduals(toas, model), name=model.PSR.value, loc=loc)
     mjd, err, freq, flags = read_tim(timfile)
-    psr = SimulatedPulsar(ephem=ephem, model=None, toas=ArrayTOAs(mjd, err, flags, freq), name=name, loc=loc)
+    with open(parfile) as fh:
+        par_text = fh.read()
+    psr = SimulatedPulsar(ephem=ephem, model=None, toas=ArrayTOAs(mjd, err, flags, freq), name=name, loc=loc, par_text=par_text)
     psr.update_residuals()
     return psr
 

@@ -327,3 +327,41 @@ def test_cw_source_params_is_bit_identical_to_the_per_source_scalar_loop():
     for pdist, pphase in ((1.0, None), (0.7, None), (1.0, 1.3)):
         assert np.array_equal(loop(pdist, pphase), det.cw_source_params(lists, phat, pdist, pphase)), (pdist, pphase)
     assert det.cw_source_params([np.zeros(0)] * 8, phat).shape == (0, det.CW_NPAR)
+
+
+def test_write_partim_round_trip_for_array_backed_pulsars(tmp_path):
+    """simulate.py:71-77 for array-backed pulsars: the tim file carries the SHIFTED TOAs at longdouble precision, the par file is the
+    one the pulsar was loaded from, verbatim (injection never changes the timing model); a pulsar built in code writes a minimal par
+    (name + position) that the par reader parses back; the idealised design matrices have full column rank."""
+    from pta_replicator_amd._compat import TimeDelta, u
+    from pta_replicator_amd.simulate import (ArrayTOAs, SimulatedPulsar, load_pulsar, make_ideal, read_par_location, read_tim,
+                                             timing_design_matrix)
+    par_src = "PSR  J1234+5678\nRAJ  12:34:56.7 1\nDECJ  -56:07:08.9 1\nF0 100.123456789 1\nPEPOCH 55000\nDM 12.5\n"
+    (tmp_path / "a.par").write_text(par_src)
+    rng = np.random.default_rng(3)
+    lines = ["FORMAT 1"] + [f" x 1440.0 {53000 + 7.3 * i:.13f} {0.5 + 0.01 * i:.3f} AXIS -f {'A' if i % 2 else 'B'} -be ASP" for i in range(40)]
+    (tmp_path / "a.tim").write_text("\n".join(lines) + "\n")
+    psr = load_pulsar(str(tmp_path / "a.par"), str(tmp_path / "a.tim"))
+    make_ideal(psr)
+    dt = rng.standard_normal(40) * 3e-6
+    psr.update_added_signals("J1234+5678_x", {}, dt * u.s)
+    psr.toas.adjust_TOAs(TimeDelta((dt * u.s).to("day")))
+    psr.update_residuals()
+    psr.write_partim(str(tmp_path / "out.par"), str(tmp_path / "out.tim"))
+    assert (tmp_path / "out.par").read_text() == par_src
+    mjd, err, freq, flags = read_tim(str(tmp_path / "out.tim"))
+    assert np.max(np.abs((mjd - psr.toas.mjd_ld).astype(np.float64))) * 86400 < 1e-9          # < 1 ns through the text round trip
+    assert np.max(np.abs((mjd - psr.toas.mjd0_ld).astype(np.float64) * 86400 - dt)) < 1e-9
+    assert flags[1] == {"f": "A", "be": "ASP"} and np.allclose(err, psr.toas.errors_us)
+    for loc in ({"RAJ": 18.961234, "DECJ": -9.72123}, {"ELONG": 286.86, "ELAT": 32.32}):
+        q = SimulatedPulsar(toas=ArrayTOAs([53000.0, 53001.0], 1.0), name="J0000+0000", loc=loc)
+        make_ideal(q)
+        q.write_partim(str(tmp_path / "q.par"), str(tmp_path / "q.tim"))
+        name, back = read_par_location(str(tmp_path / "q.par"))
+        assert name == "J0000+0000" and set(back) == set(loc) and all(abs(back[k] - loc[k]) < 1e-9 for k in loc)
+    t = np.sort(rng.uniform(53000, 58000, 400)) * 86400.0
+    for model, m in (("spin", 3), ("astrometric", 9)):
+        M, names = timing_design_matrix(t, model=model)
+        assert M.shape == (400, m) and len(names) == m and np.linalg.matrix_rank(M) == m and np.max(np.abs(M)) <= 1.0 + 1e-12
+    with pytest.raises(ValueError):
+        timing_design_matrix(t, model="binary")
