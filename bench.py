@@ -16,7 +16,7 @@ Besides the contract fields the line carries
   roofline      the dominant kernel of the step against its bound: algorithmic units per launch / launch time measured
                 here with HIP events on the launch stream; HBM peak 8 TB/s (MI355X_MICROARCH.md); fp64 matrix peak
                 78.6 TFLOP/s = AMD's public MI355X figure, cross-checked by the in-library microbenchmark.  `traffic`
-                (PMC HBM bytes per launch) comes from the committed rocprofv3 passes in profiles/r02_pmc.json and is
+                (PMC HBM bytes per launch) comes from the committed rocprofv3 passes in profiles/r03_pmc.json and is
                 quoted only while launch shape and kernel sources match that profile - otherwise null with the reason
   kernels_ms    per-kernel times of one step (HIP events)
   td_mode       the dense path of the north_star on the same array: covariance assembly, batched fp64 Cholesky
@@ -106,14 +106,14 @@ def src_sha(*files):
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 CZT_SRC = ("pta_czt_kernels.hip", "pta_fft.h", "pta_rng.h", "pta_rng_tables.h")
 
 
 def pmc_entry(key, srcs, **shape):
-    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r2.sh -> profiles/r02_pmc.json),
+    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r3.sh -> profiles/r03_pmc.json),
     or (None, reason) when the file is missing, was taken at another launch shape, or the kernel sources changed since."""
     try:
         with open(PMC_FILE) as fh:
@@ -290,11 +290,15 @@ def td_mode_numbers(eng, R):
     res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
                 "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "gw_grid_factor_jitter": eng.gw_td_jitter if eng.plan.gw_npts else None})
-    for key, name in (("k_dgemm_mfma128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng", "trmm_mfma_busy_pct")):
+    for key, name in (("k_dgemm_glds128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng", "trmm_mfma_busy_pct"),
+                      ("k_td_cov128", "cov_assemble_mfma_busy_pct")):
         e, why = pmc_entry(key, TD_SRC, n_psr=eng.P)
         res[name] = e["mfma_busy_pct"] if e else None
         if e:
             res[name + "_source"] = e.get("source")
+            if key == "k_td_cov128" and e.get("hbm_write_GBps"):   # counter bytes (WRITE_SIZE) over the rocprofv3 launch time
+                res["cov_assemble_GBps_from_WRITE_SIZE"] = e["hbm_write_GBps"]
+                res["cov_assemble_write_bytes_pmc"] = e["write_kib_per_dispatch"] * 1024.0
         else:
             res[name + "_note"] = why
     return res
@@ -311,6 +315,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-td", action="store_true", help="skip the TD-mode (dense covariance / Cholesky / L.z) measurement")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the timed generate+gather-to-rank-0 pipeline")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (config-4 shape, drop-in API timing): profiling runs")
     args = ap.parse_args()
 
     import torch
@@ -422,10 +427,11 @@ def main():
                             "realisation ranges by shard_range(); generation only (the gather to rank 0 is `gathered_to_rank0`)"}
 
     cfg4 = None
-    try:
-        cfg4 = config4_shape()
-    except Exception as e:  # pragma: no cover
-        cfg4 = {"error": str(e)[:300]}
+    if not args.no_extras:
+        try:
+            cfg4 = config4_shape()
+        except Exception as e:  # pragma: no cover
+            cfg4 = {"error": str(e)[:300]}
 
     # ---- per-kernel times of one step: HIP events on the stream the kernels are launched on ----
     kern = {}
@@ -509,7 +515,7 @@ def main():
         ach = alg_bytes / (kern[k] * 1e-3) / 1e9
         d = {"kernel": k, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
              "traffic": None, "avg_launch_ms": kern[k]}
-        e, why = pmc_entry("k_engine_synth_mfma<false>", SYNTH_SRC, R=R, n_toa=eng.n_toa)
+        e, why = pmc_entry("k_engine_synth_mfma<false, false>", SYNTH_SRC, R=R, n_toa=eng.n_toa)
         if e:   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB) of this very launch shape and these very sources
             d["traffic"] = (e["fetch_kib"] + e["write_kib"]) * 1024.0
             d["traffic_source"] = e.get("source")
@@ -614,7 +620,7 @@ def main():
         line["td_mode"] = td
     if cfg4 is not None:
         line["config4_shape"] = cfg4
-    if world == 1:
+    if world == 1 and not args.no_extras:
         try:
             api = api_mode_timing(psrs, noise)
             line["api_mode_ms"] = api["loop"]["total"]

@@ -406,25 +406,22 @@ static int pta_potrf_step(double *A, int n, int64_t lda, int64_t strideA, int B,
   return pta_dgemm_launch(1, rows, rows, nbo, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
 }
 
-// ---- panel solve through the explicit inverse of the panel's diagonal block (pta_potrf_batched_ws) ---------------------------
+// ---- panel solve on the rows BELOW the panel only, through 128 x 128 inverses of the diagonal blocks (pta_potrf_batched_ws) ----
 // pta_factor_panel above applies its recursion to the FULL height of a panel: every 64-column solve, K = 64 update and K = 128 /
-// 256 / 512 product touches all rows below - ~1200 dispatches per 68-matrix batch, most of them latency chains that need the whole
-// machine's wave slots to finish in their 40 us and therefore do NOT overlap another chain's trailing update (whose workgroups hold
-// those slots), and 29 % of the flops at K <= 512, where the tile kernel runs at 45-63 TFLOP/s instead of 66.  With a workspace the
-// same panel becomes
-//   (1) the recursion on the nbo x nbo DIAGONAL block only (rows = nbo: a fifth of the work at n = 5000, a few workgroups per
-//       launch - they slip into any free slot);
-//   (2) W = L11^{-1} (lower triangular, nbo x nbo) built from the 64 x 64 inverses k_potf2 parks: 128-blocks by one small kernel,
-//       then block row i from   W[i, <i] = -W_ii (L11[i, <i] W[<i, <i])   - two small products per 128 rows;
-//   (3) X = B W^T for ALL rows below, in place, one 128-column block at a time in DESCENDING order (block j needs B's columns
-//       [0, 128 (j + 1)) only, so the blocks to its right may already hold X): each a tile product with K = 128 (j + 1), flop
-//       count of the triangular solve it replaces;
+// 256 / 512 product touches all rows below - ~1200 dispatches per 68-matrix batch, most of them latency chains.  With a workspace
+// the same panel becomes
+//   (1) the recursion on the nbo x nbo DIAGONAL block only (rows = nbo: a fifth of the work at n = 5000);
+//   (2) W_jj = (L11's 128 x 128 diagonal block j)^-1 for all j at once, from the 64 x 64 inverses k_potf2 parks (k_inv_blocks);
+//   (3) blocked substitution over the 128-column blocks, left to right, on ALL rows below, two tile products per block:
+//         B_j -= X_{<j} L11[j, <j]^T        (K = 128 j; X_{<j} are the finished blocks to the left)
+//         X_j  = B_j W_jj^T                 (K = 128; in place: one column tile per launch reads its columns before it writes them)
 //   (4) the trailing update as before (K = nbo).
-// cond(L11) * eps enters X (as it already does through the 64 x 64 inverses): the TD covariances have cond(L) ~ 1e2-1e4, their
-// factors agree with LAPACK to 1e-10 (tests); ill-conditioned inputs take PTA_POTRF_SUBSTITUTION and the workspace-free path.
+// cond(L11's diagonal blocks) * eps enters X, as it already does through the 64 x 64 inverses: the TD covariances have cond(L) ~
+// 1e2-1e4, their factors agree with LAPACK to 1e-10 (tests); ill-conditioned inputs take PTA_POTRF_SUBSTITUTION (workspace ignored).
 
 // one workgroup per (128-column block, matrix): W block = [[X1, 0], [-X2 L21 X1, X2]] from the two 64 x 64 (first block: narrower)
-// diagonal tiles as k_potf2 left them - L below the diagonal, X^T = L^{-T} above it, X's diagonal = 1 / L's.
+// diagonal tiles as k_potf2 left them - L below the diagonal, X^T = L^{-T} above it, X's diagonal = 1 / L's.  Tiles are read along
+// their rows (coalesced) and transposed on the way into LDS.
 __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A, int64_t lda, int64_t sA, int k0, int nbo, int f128,
                                                     double *__restrict__ W, int64_t ldw, int64_t sW) {
   __shared__ double X1[64][65], X2[64][65], L21[64][65], T[64][65];
@@ -433,19 +430,20 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
   const int wd = blk == 0 ? f128 : 128;                     // its width
   const int w1 = wd > 64 ? wd - 64 : wd, w2 = wd - w1;      // base blocks inside it (w2 = 64 or 0)
   const double *M = A + (int64_t)blockIdx.y * sA + (int64_t)(k0 + o) * lda + (k0 + o);
-  double *Wb = W + (int64_t)blockIdx.y * sW + (int64_t)o * ldw + o;
+  double *Wb = W + (int64_t)blockIdx.y * sW + (int64_t)blk * 128 * ldw;   // W_jj of block j at rows [128 j, 128 j + 128) of the workspace
   const int t = threadIdx.x;
   for (int idx = t; idx < 64 * 64; idx += 256) {
-    const int r = idx >> 6, c = idx & 63;
+    const int r = idx >> 6, c = idx & 63;  // tile element (r, c), c fastest: coalesced
     double x1 = 0.0, x2 = 0.0, l = 0.0;
-    if (r < w1 && c < w1) x1 = c < r ? M[(int64_t)c * lda + r] : (c == r ? 1.0 / M[(int64_t)r * lda + r] : 0.0);
+    if (r < w1 && c < w1 && c >= r) x1 = M[(int64_t)r * lda + c];
     if (w2) {
       const double *M2 = M + (int64_t)w1 * lda + w1;
-      x2 = c < r ? M2[(int64_t)c * lda + r] : (c == r ? 1.0 / M2[(int64_t)r * lda + r] : 0.0);
+      if (c >= r) x2 = M2[(int64_t)r * lda + c];
       if (c < w1) l = M[(int64_t)(w1 + r) * lda + c];
     }
-    X1[r][c] = x1;
-    X2[r][c] = x2;
+    // element (r, c) above the diagonal is X[c][r]; on it, 1 / L[r][r]
+    X1[c][r] = (r < w1 && c < w1 && c >= r) ? (c == r ? 1.0 / x1 : x1) : 0.0;
+    X2[c][r] = (w2 && c >= r) ? (c == r ? 1.0 / x2 : x2) : 0.0;
     L21[r][c] = l;
   }
   __syncthreads();
@@ -460,39 +458,33 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
   }
   for (int idx = t; idx < 128 * 128; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
-    if (r >= wd || c >= wd) continue;
     double v = 0.0;
-    if (r < w1) v = c < w1 ? X1[r][c] : 0.0;
-    else if (c >= w1) v = X2[r - w1][c - w1];
-    else {
-      double acc = 0.0;
-      for (int k = 0; k <= r - w1; ++k) acc = fma(X2[r - w1][k], T[k][c], acc);  // X2 lower triangular: k <= r
-      v = -acc;
+    if (r < wd && c < wd) {
+      if (r < w1) v = c < w1 ? X1[r][c] : 0.0;
+      else if (c >= w1) v = X2[r - w1][c - w1];
+      else {
+        double acc = 0.0;
+        for (int k = 0; k <= r - w1; ++k) acc = fma(X2[r - w1][k], T[k][c], acc);  // X2 lower triangular: k <= r
+        v = -acc;
+      }
     }
-    Wb[(int64_t)r * ldw + c] = v;
-  }
-  // the blocks to the RIGHT of this one (above W's block diagonal) are read by the products that build the block rows below, as part
-  // of the square W[0:oi, 0:oi): they must be zero, and the workspace arrives uninitialised
-  const int right = nbo - (o + wd);
-  for (int64_t idx = t; idx < (int64_t)wd * right; idx += 256) {
-    const int r = (int)(idx / right), c = (int)(idx - (int64_t)r * right);
-    Wb[(int64_t)r * ldw + wd + c] = 0.0;
+    Wb[(int64_t)r * ldw + c] = v;   // the whole 128 x 128 slot is written (zeros outside the block): the products read K = 128 of it
   }
 }
 
-#define PTA_POTRF_WS_LD(NBO) ((NBO) + 128)   // leading dimension of W and of the scratch strip: the widest panel is NBO + 127 columns
+#define PTA_POTRF_WS_LD 128   // leading dimension of the workspace: one 128 x 128 inverse per 128-column block of a panel
 
 extern "C" int64_t pta_potrf_workspace_doubles(int n, int B, int flags) {
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;
   if (n <= NBO || B <= 0 || (flags & (PTA_POTRF_VALU | PTA_POTRF_SUBSTITUTION))) return 0;
-  const int64_t ldw = PTA_POTRF_WS_LD(NBO);
-  return (int64_t)B * (ldw * ldw + 128 * ldw);
+  const int64_t nblk = (NBO + 127 + 127) / 128;  // the widest panel is NBO + 127 columns
+  return (int64_t)B * nblk * 128 * PTA_POTRF_WS_LD;
 }
 
 // One step of a chain with the workspace scheme; returns the next panel's first column in *k0_io.
 static int pta_potrf_step_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, int *k0_io,
-                             double *W, hipStream_t s, hipEvent_t ev_after_diag) {
+                             double *W, int64_t sW, hipStream_t s, hipEvent_t ev_after_diag) {
   const int k0 = *k0_io;
   const int want = (k0 == 0 && n > NBO) ? NBO + (n % 128) : NBO;
   const int nbo = (n - k0 < want) ? (n - k0) : want;
@@ -503,34 +495,29 @@ static int pta_potrf_step_ws(double *A, int n, int64_t lda, int64_t strideA, int
   *k0_io = pend;
   const int rows = n - pend;
   if (rows <= 0) return PTA_OK;
-  const int64_t ldw = PTA_POTRF_WS_LD(NBO), sW = ldw * ldw + 128 * ldw;
-  double *T = W + ldw * ldw;  // [128 x ldw] strip per matrix
-  // (2) W = L11^{-1}
+  const int64_t ldw = PTA_POTRF_WS_LD;
+  // (2) the 128 x 128 inverses of the diagonal blocks
   const int nb = (nbo + 127) / 128, f128 = nbo - 128 * (nb - 1);  // first block narrower when nbo % 128 != 0
   hipLaunchKernelGGL(k_inv_blocks, dim3(nb, B), dim3(256), 0, s, A, lda, strideA, k0, nbo, f128, W, ldw, sW);
   PTA_LAUNCH_CHECK();
-  const double *L11 = A + (int64_t)k0 * lda + k0;
-  for (int i = 1; i < nb; ++i) {
-    const int oi = f128 + 128 * (i - 1);
-    // T = L11[i-rows, 0:oi) . W[0:oi, 0:oi)        (W as the [K x N] operand)
-    rc = pta_dgemm_launch(0, 128, oi, oi, 1.0, L11 + (int64_t)oi * lda, lda, 1, W, ldw, 0.0, T, ldw, 0, B, strideA, sW, sW, 1, s);
-    if (rc != PTA_OK) return rc;
-    // W[i-rows, 0:oi) = -W_ii . T
-    rc = pta_dgemm_launch(0, 128, oi, 128, -1.0, W + (int64_t)oi * ldw + oi, ldw, 1, T, ldw, 0.0, W + (int64_t)oi * ldw, ldw, 0, B, sW, sW, sW, 1, s);
-    if (rc != PTA_OK) return rc;
-  }
   if (ev_after_diag) PTA_HIP(hipEventRecord(ev_after_diag, s));
-  // (3) X = B W^T in place, 128-column blocks right to left
+  // (3) blocked substitution on the rows below, left to right
+  const double *L11 = A + (int64_t)k0 * lda + k0;
   double *Bp = A + (int64_t)pend * lda + k0;
-  for (int j = nb - 1; j >= 0; --j) {
+  for (int j = 0; j < nb; ++j) {
     const int oj = j == 0 ? 0 : f128 + 128 * (j - 1), wj = j == 0 ? f128 : 128;
-    // in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so a block
-    // the launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left as well
-    const int tile = pta_dgemm_tile_n(rows, wj, oj + wj, algo);
+    if (j > 0) {  // B_j -= X_{<j} L11[j, <j]^T
+      rc = pta_dgemm_launch(1, rows, wj, oj, -1.0, Bp, lda, 1, L11 + (int64_t)oj * lda, lda, 1.0, Bp + oj, lda, 0, B, strideA, strideA, strideA, algo, s);
+      if (rc != PTA_OK) return rc;
+    }
+    // X_j = B_j W_jj^T, in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so
+    // a block the launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left (chunk [c0, c1)
+    // needs the block's columns [0, c1) only: W_jj is lower triangular)
+    const int tile = pta_dgemm_tile_n(rows, wj, wj, algo);
     for (int c1 = wj; c1 > 0; c1 -= tile) {
       const int c0 = c1 > tile ? c1 - tile : 0;
-      rc = pta_dgemm_launch(1, rows, c1 - c0, oj + c1, 1.0, Bp, lda, 1, W + (int64_t)(oj + c0) * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B, strideA, sW,
-                            strideA, algo, s);
+      rc = pta_dgemm_launch(1, rows, c1 - c0, c1, 1.0, Bp + oj, lda, 1, W + (int64_t)j * 128 * ldw + (int64_t)c0 * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B,
+                            strideA, sW, strideA, algo, s);
       if (rc != PTA_OK) return rc;
     }
   }
@@ -569,7 +556,7 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   const bool use_ws = work != nullptr && need > 0 && work_doubles >= need && algo;
   const int64_t sWm = use_ws ? need / B : 0;  // workspace doubles per matrix
   auto chain_step = [&](double *Ab, int Bc, int32_t *infob, double *Wb, int *k0p, hipStream_t st, hipEvent_t ev) {
-    return use_ws ? pta_potrf_step_ws(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, Wb, st, ev)
+    return use_ws ? pta_potrf_step_ws(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, Wb, sWm, st, ev)
                   : pta_potrf_step(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, st);
   };
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));

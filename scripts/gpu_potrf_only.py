@@ -9,5 +9,6 @@ look = sys.argv[3] != "0"
 psrs, noise = headline_array(P, N)
 eng = configure_engine(ReplicaEngine(psrs, seed=1), noise)
 eng._gw = None
+eng.td_potrf_workspace = len(sys.argv) > 4 and sys.argv[4] == "ws"
 eng.prepare_td(lookahead=look)
 torch.cuda.synchronize()

@@ -1,7 +1,7 @@
 # per-kernel table + queue-overlap of ONE prepare_td (assembly + workspace-scheme factorisation of 68 x 5000^2)
 cd $GRAFT_REPO_ROOT && export PYTHONUNBUFFERED=1 TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/potrf_tl; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT/run -o t -- python scripts/gpu_potrf_only.py 68 5000 ${1:-1} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/run -o t -- python scripts/gpu_potrf_only.py 68 5000 ${1:-1} ${2:-ws} > $OUT/run.log 2>&1
 tail -3 $OUT/run.log
 python scripts/prof_summary.py $OUT/run --timeline | head -40
 python - <<PY

@@ -1,4 +1,4 @@
-"""Turn the rocprofv3 CSV passes of scripts/gpu_profile_r2.sh into profiles/r02_pmc.json: the PMC figures bench.py quotes
+"""Turn the rocprofv3 CSV passes of scripts/gpu_profile_r3.sh into profiles/r03_pmc.json: the PMC figures bench.py quotes
 (roofline.traffic, VALU issue, MFMA-busy %), each keyed by kernel + launch shape + a hash of the kernel sources."""
 import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,7 +35,7 @@ res = {}
 SIMD_PER_XCD = 128   # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (checked: value / kernel duration = 8 x ~2 GHz), so
                      # GUI_ACTIVE x 128 SIMDs per XCD = SIMD-cycles of the whole chip during the dispatch
 # ---- fused synthesis kernel
-k = "k_engine_synth_mfma<false>"
+k = "k_engine_synth_mfma<false, false>"
 f, nf = sums("pmc_fetch", k)
 w, nw = sums("pmc_write", k)
 a, na = sums("pmc_sq", k)
@@ -43,7 +43,7 @@ ms, nt = avg_ms(k)
 if nf and nw:
     e = {"R": R, "n_toa": n_toa, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
          "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*SYNTH_SRC),
-         "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
+         "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
     if na:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE"):
@@ -59,23 +59,32 @@ ms, nt = avg_ms(k)
 if nf and nw:
     e = {"rows": R * n_psr, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
          "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*CZT_SRC),
-         "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
+         "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
     if na:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE") and a.get("SQ_ACTIVE_INST_VALU"):
             e["valu_busy"] = a["SQ_ACTIVE_INST_VALU"] * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD)
             e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
     res[k] = e
-# ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches
-for k in ("k_dgemm_mfma128", "k_td_trmm_rng", "k_td_cov128", "k_trsm_mfma", "k_mb_mfma(", "k_mb_mfma_tile("):
+# ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches; HBM bytes from
+# the FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch; this round those passes run WITH TD mode)
+for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_cov128", "k_trsm_mfma", "k_potf2", "k_mb_mfma(", "k_mb_mfma_tile("):
     m, nm = sums("pmc_mfma", k)
     ms, nt = avg_ms(k)
     if nm and m.get("GRBM_GUI_ACTIVE"):
-        res[k] = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD),
-                  "executed_TFLOPs": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 64 * 2048 / (ms * 1e-3) / 1e12 if ms else None,
-                  "engine_clock_GHz_under_pmc": m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None,
-                  "mfma_busy_cycles_per_dispatch": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active_cycles_per_dispatch": m["GRBM_GUI_ACTIVE"],
-                  "insts_valu_per_dispatch": m.get("SQ_INSTS_VALU"), "avg_launch_ms_rocprof": ms, "dispatches": nm, "src_sha": src_sha(*TD_SRC),
-                  "source": "profiles/r02_rocprofv3_summary.txt (scripts/gpu_profile_r2.sh)"}
-json.dump(res, open(os.path.join(out_dir, "r02_pmc.json"), "w"), indent=1)
+        e = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD),
+             "executed_TFLOPs": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 64 * 2048 / (ms * 1e-3) / 1e12 if ms else None,
+             "engine_clock_GHz_under_pmc": m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None,
+             "mfma_busy_cycles_per_dispatch": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active_cycles_per_dispatch": m["GRBM_GUI_ACTIVE"],
+             "insts_valu_per_dispatch": m.get("SQ_INSTS_VALU"), "avg_launch_ms_rocprof": ms, "dispatches": nm, "src_sha": src_sha(*TD_SRC),
+             "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
+        f, nf = sums("pmc_fetch", k)
+        w, nw = sums("pmc_write", k)
+        if nf and nw:
+            e["fetch_kib_per_dispatch"], e["write_kib_per_dispatch"] = f.get("FETCH_SIZE"), w.get("WRITE_SIZE")
+            if ms:
+                e["hbm_write_GBps"] = w.get("WRITE_SIZE", 0.0) * 1024.0 / (ms * 1e-3) / 1e9
+                e["hbm_fetch_GBps_uncorrected"] = f.get("FETCH_SIZE", 0.0) * 1024.0 / (ms * 1e-3) / 1e9
+        res[k] = e
+json.dump(res, open(os.path.join(out_dir, "r03_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
