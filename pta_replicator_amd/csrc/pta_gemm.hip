@@ -314,6 +314,12 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
 //     4 t + q): a lane's four A (or B) values of a slab are 32 contiguous bytes of its row = two ds_read_b128 instead of four
 //     ds_read_b64, 16 per wave and slab in all, issued as two waves of eight so that the first 32 MFMAs start while the second
 //     half is still landing.
+// Where the rest goes (throw-away probe builds, M = N = 3968 lower / 4096 full, batch 34 / 16, beta = 0): the loop without its DMA runs
+// at 70.4 TFLOP/s at K = 1024 and 75.2 at K = 4096 (96 % of the 78.6 peak: fragment reads and barriers cost nothing); issuing the
+// eight DMA pieces per slab costs 3 %, waiting for them to land at the closing barrier another 5 % (issue -> landed is ~1 us under
+// this load, a slab lasts ~2.5 us) - 64.9 / 70.9 as shipped.  Issuing the DMA at the top of the slab instead of behind the first 16
+// MFMAs: no change; an XCD-contiguous tile order (each XCD walking neighbouring tiles of one matrix): no change at K = 1024, -4 % at
+// K = 4096 - the operands come from the 256 MB memory-side cache either way.  A deeper ring (four stages of 8 k) is the next step.
 // Rows past M / N and k past K are fetched from clamped (valid) addresses; a K tail (K % 16 != 0) zeroes the fragments of the
 // slots past K in registers, in the last iteration only.  Requirements as for VEC: transB, unit k stride, even K and leading
 // dimensions, 16-byte aligned operands.
