@@ -319,7 +319,10 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_mfma128(int M, int N, int K, d
 // eight DMA pieces per slab costs 3 %, waiting for them to land at the closing barrier another 5 % (issue -> landed is ~1 us under
 // this load, a slab lasts ~2.5 us) - 64.9 / 70.9 as shipped.  Issuing the DMA at the top of the slab instead of behind the first 16
 // MFMAs: no change; an XCD-contiguous tile order (each XCD walking neighbouring tiles of one matrix): no change at K = 1024, -4 % at
-// K = 4096 - the operands come from the 256 MB memory-side cache either way.  A deeper ring (four stages of 8 k) is the next step.
+// K = 4096 - the operands come from the 256 MB memory-side cache either way; a deeper ring (four stages of 8 k, the DMA of stage
+// s + 3 in flight across raw s_barriers with counted vmcnt(8) waits, one ds_read_b128 per fragment): 65.2 / 60.8 / 42.1 / 70.6 at
+// K = 1024 / 512 / 128 / 4096 against 66.2 / 63.0 / 45.6 / 70.6 - the wait moves, the total does not: what the DMA costs is its
+// share of the LDS write path and of the texture addresser, not its latency.
 // Rows past M / N and k past K are fetched from clamped (valid) addresses; a K tail (K % 16 != 0) zeroes the fragments of the
 // slots past K in registers, in the last iteration only.  Requirements as for VEC: transB, unit k stride, even K and leading
 // dimensions, 16-byte aligned operands.
