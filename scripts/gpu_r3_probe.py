@@ -51,7 +51,8 @@ if "potrf" in what:
     work.fill_(float("nan"))
     for name, flags, ws in (("reg_2chains", RS, 0), ("glds_2chains", 0, 0), ("ws_1chain", _lib.POTRF_NO_LOOKAHEAD, 1), ("ws_2chains", 0, 1),
                             ("ws_2chains_lockstep", _lib.POTRF_LOCKSTEP, 1), ("ws_3chains", _lib.POTRF_CHAINS(3), 1), ("ws_4chains", _lib.POTRF_CHAINS(4), 1),
-                            ("ws_2chains_nb512", _lib.POTRF_NB(2), 2), ("ws_3chains_nb512", _lib.POTRF_NB(2) | _lib.POTRF_CHAINS(3), 2)):
+                            ("ws_2chains_nb512", _lib.POTRF_NB(2), 2), ("ws_2chains_nb1536", _lib.POTRF_NB(6), 2), ("ws_2chains_nb2048", _lib.POTRF_NB(8), 2),
+                            ("glds_2chains_nb2048", _lib.POTRF_NB(8), 0), ("glds_2chains_nb1536", _lib.POTRF_NB(6), 0)):
         if ws == 2:
             need2 = int(_lib.lib.pta_potrf_workspace_doubles(n, P, flags))
             work = dv.empty((need2,)); need = need2
