@@ -284,11 +284,19 @@ def td_mode_numbers(eng, R):
                     "potrf_ms": tp * 1e3, "potrf_TFLOPs": flop_chol / tp / 1e12, "potrf_frac_of_fp64_mfma_peak": flop_chol / tp / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "positive_definite": int(info.abs().sum().item()) == 0})
     out = dv.empty((R, eng.n_toa))
+    # the same realisations two ways: deviates generated inside the product's loop ("registers", no buffer) and written once per batch
+    # and read by the product ("memory", the default)
+    eng.td_draws = "registers"
+    eng.generate_td(R, out=out)
+    t_reg = wall(lambda: eng.generate_td(R, out=out), 2)
+    eng.td_draws = "memory"
     eng.generate_td(R, out=out)
     t = wall(lambda: eng.generate_td(R, out=out), 2)
     flop = float(sum(n * n for n in counts))       # useful flops per realisation of L.z (triangular): sum N_a^2
     res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
                 "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                "td_draws": "memory (deviates written once per batch, read by the product)",
+                "draws_in_registers": {"generate_td_ms": t_reg * 1e3, "realisations_per_s": R / t_reg, "trmm_useful_TFLOPs": flop * R / t_reg / 1e12},
                 "gw_grid_factor_jitter": eng.gw_td_jitter if eng.plan.gw_npts else None})
     for key, name in (("k_dgemm_glds128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng", "trmm_mfma_busy_pct"),
                       ("k_td_cov128", "cov_assemble_mfma_busy_pct")):

@@ -388,6 +388,12 @@ typedef struct {
   const int32_t *gw_jlo;
   const double *gw_w;
   const double *det;          /* NULL = none */
+  const double *z;            /* ABI 3, rows_per_real == 1 only: NULL = every deviate is generated in registers (default); else the deviates
+                                 are READ: z[m * ld_z + blk_zoff[b] + j] = deviate j of row m for factor block b - what pta_rng_fill_normal
+                                 (interleave = 1) writes for stream (stream_kind, b).  Same numbers either way, bit-identical output.
+                                 Every row needs 16 finite doubles behind its last block (ld_z >= blk_zoff[last] + blk_n[last] + 16) */
+  int64_t ld_z;
+  const int32_t *blk_zoff;    /* [n_blocks] first column of block b's deviates inside a row of z (even: pta_rng_fill_normal writes pairs) */
 } pta_td_plan;
 
 int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out, void *stream);

@@ -324,7 +324,12 @@ __device__ __forceinline__ int pta_td_swz(int row) {
   return (e & 1) | (((e >> 2) & 1) * 6);
 }
 
-template <bool FAST>
+// ZMEM: the deviates are READ (pl.z, the same numbers pta_rng_fill_normal writes for stream (TD, pulsar)) instead of generated: lane
+// (c, q) needs z[m][k0 + 4 q .. + 3] of its own Z row - 32 contiguous bytes that no other wave uses, so they go from global memory
+// straight into the MFMA A operand registers (no LDS), requested one slab ahead.  Same deviates, same MFMA order: bit-identical
+// output; what it buys is the matrix pipe's time - two fp64 Box-Muller pairs per lane and slab share the double-precision ALUs with
+// the MFMAs - for 8 bytes of traffic per deviate and strip.
+template <bool FAST, bool ZMEM>
 __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t seed, uint64_t r0, int M, double *__restrict__ out,
                                                         int64_t ld_out) {
   constexpr int fast = FAST ? 1 : 0;
@@ -391,14 +396,32 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
 
   // one slab: two Box-Muller pairs (this lane's four deviates), 32 fragment reads, 64 MFMAs.  MASK: the slab crosses the strip's
   // diagonal block - entries with k > row are not part of L
+  // ZMEM: this lane's Z row, and the two 16-byte pieces of the slab about to be multiplied (requested during the previous slab)
+  typedef double pta_f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+  const double *__restrict__ zrow = nullptr;
+  pta_f64x2_a8 zn0 = {0.0, 0.0}, zn1 = {0.0, 0.0};
+  auto zfetch = [&](int k0) {  // a slab may reach up to 15 columns past the factor's order: the next block's deviates or the row's padding
+    const int kk = k0 + 4 * q;  // (finite either way, and multiplied by masked - zero - entries of L)
+    zn0 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk);
+    zn1 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk + 2);
+  };
+  if (ZMEM) {
+    zrow = pl.z + (int64_t)min(m_a, M - 1) * pl.ld_z + pl.blk_zoff[blk];
+    zfetch(0);
+  }
   auto slab = [&](int s, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int cur = s & 1, k0 = s * TDS_K;
     const char *pb = reinterpret_cast<const char *>(&Bs[cur][0]) + offc;
     double z[4];
-    const uint32_t p0 = (uint32_t)((k0 >> 1) + 2 * q);
-    pta_normal_pair(seed, real_a, strm_a, p0, z[0], z[1], fast);
-    pta_normal_pair(seed, real_a, strm_a, p0 + 1u, z[2], z[3], fast);
+    if (ZMEM) {
+      z[0] = zn0.x, z[1] = zn0.y, z[2] = zn1.x, z[3] = zn1.y;
+      if (s + 1 < nslab) zfetch(k0 + TDS_K);
+    } else {
+      const uint32_t p0 = (uint32_t)((k0 >> 1) + 2 * q);
+      pta_normal_pair(seed, real_a, strm_a, p0, z[0], z[1], fast);
+      pta_normal_pair(seed, real_a, strm_a, p0 + 1u, z[2], z[3], fast);
+    }
     const int kq = k0 + 4 * q;  // this lane's first k of the slab
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -423,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
     __syncthreads();
   };
   stage(0, 0);
-  pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
+  if (!ZMEM) pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
   __syncthreads();
   const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 256)
   int s = 0;
@@ -477,10 +500,14 @@ extern "C" int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint
   const int64_t nmg = pta_cdiv(M, TDS_M);
   const int64_t nwg = p.n_items >= TDS_MANY_ITEMS ? (int64_t)((p.n_items + 7) / 8) * 8 * nmg : (int64_t)p.n_items * ((nmg + 7) / 8) * 8;
   PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_td_trmm_rng: %lld workgroups exceed one launch", (long long)nwg);
-  if (p.rng_fast)
-    hipLaunchKernelGGL(k_td_trmm_rng<true>, dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
+  if (p.z) {
+    PTA_REQUIRE(p.rows_per_real == 1 && p.ld_z >= 4 && p.blk_zoff, PTA_E_ARG,
+                "pta_td_trmm_rng: supplied deviates (plan.z) need rows_per_real == 1, blk_zoff and ld_z");
+    hipLaunchKernelGGL((k_td_trmm_rng<false, true>), dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
+  } else if (p.rng_fast)
+    hipLaunchKernelGGL((k_td_trmm_rng<true, false>), dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
   else
-    hipLaunchKernelGGL(k_td_trmm_rng<false>, dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
+    hipLaunchKernelGGL((k_td_trmm_rng<false, false>), dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

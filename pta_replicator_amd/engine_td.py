@@ -169,11 +169,31 @@ class TimeDomainMixin:
             if ws is None or ws[0].shape[0] < chunk:
                 ws = self._td_ws = (dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts)))
             tp.gw_G = ws[1].data_ptr()
+        from .engine import stream_id
+        # "memory" (default): the deviates of a batch are written once (pta_rng_fill_normal, 8 bytes each: 2.8 GB per 1024 realisations of
+        # the 68 x 5000 array) and READ by the product; "registers": generated inside the product's loop (no buffer) - the same numbers,
+        # bit-identical realisations; 31.2 against 35.0 ms per 1024 (the fp64 Box-Muller shares the double-precision ALUs with the MFMAs)
+        zmem = getattr(self, "td_draws", "memory") == "memory"
+        if zmem:   # the deviates are written once per batch (8 bytes each) and READ by the product instead of being generated in its loop
+            chunk = int(min(chunk, 1024))
+            zoff = np.concatenate([[0], np.cumsum((self.counts + 1) // 2 * 2)]).astype(np.int64)   # every block starts on an even column
+            zb = getattr(self, "_td_zbuf", None)
+            if zb is None or zb.shape[0] < chunk or zb.shape[1] != int(zoff[-1]) + 16:
+                zb = self._td_zbuf = dv.zeros((chunk, int(zoff[-1]) + 16))
+                self._td_zoff = dv.i32(zoff[:-1])
+            tp.z, tp.ld_z, tp.blk_zoff = zb.data_ptr(), zb.stride(0), self._td_zoff.data_ptr()
+        else:
+            tp.z, tp.ld_z, tp.blk_zoff = None, 0, None
         for lo in range(0, R, chunk):
             n = min(chunk, R - lo)
             if npts:
                 _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(ws[0]), npts, s)
                 _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), int(self.mix_variant), s)
+            if zmem:
+                for a in range(P):
+                    na = int(self.counts[a])
+                    _lib.call("pta_rng_fill_normal", self.seed, r0 + lo, n, stream_id(STREAM_TD, a), (na + 1) // 2, 1,
+                              ctypes.c_void_p(zb.data_ptr() + 8 * int(zoff[a])), None, zb.stride(0), int(self.rng_fast), s)
             _lib.call("pta_td_trmm_rng", ctypes.byref(tp), self.seed, r0 + lo, n, ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)),
                       out.stride(0), s)
         return out

@@ -15,3 +15,10 @@ for _ in range(3):
 fl = float(sum(int(c) ** 2 for c in eng.counts))
 t = min(ts)
 print(json.dumps({"prepare_td_ms": t_prep * 1e3, "generate_td_ms": [round(x * 1e3, 2) for x in ts], "realisations_per_s": R / t, "trmm_useful_TFLOPs": fl * R / t / 1e12}))
+eng.td_draws = "memory"
+eng.generate_td(R, out=out); torch.cuda.synchronize()
+ts = []
+for _ in range(3):
+    t0 = time.perf_counter(); eng.generate_td(R, out=out); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+t = min(ts)
+print(json.dumps({"td_draws": "memory", "generate_td_ms": [round(x * 1e3, 2) for x in ts], "realisations_per_s": R / t, "trmm_useful_TFLOPs": fl * R / t / 1e12}))

@@ -347,3 +347,34 @@ def test_td_engine_fast_rng_math_is_self_consistent():
     assert 0 < np.max(np.abs(out - ref)) < 1e-3 * np.sqrt(np.mean(ref ** 2))
     eng.rng_fast = 0
     assert np.array_equal(eng.generate_td(3, r0=5).cpu().numpy(), ref)
+
+
+def test_td_draws_from_memory_equal_draws_in_registers():
+    """ReplicaEngine.td_draws = "memory": the product READS its deviates (pta_td_plan.z, written once per batch by pta_rng_fill_normal)
+    instead of generating them in its loop - same numbers, same MFMA order: bit-identical realisations, on ragged pulsars with odd
+    TOA counts, a realisation count that is not a multiple of the 64-row groups, GWB + deterministic epilogue included."""
+    import torch
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    rng = np.random.default_rng(8)
+    psrs = []
+    for a, n in enumerate((777, 300, 1025)):
+        p = SimulatedPulsar(toas=ArrayTOAs(np.sort(rng.uniform(53000, 56000, n)), rng.uniform(0.3, 1.5, n)), name=f"J{a:04d}",
+                            loc={"RAJ": 2.0 + 3 * a, "DECJ": -20.0 + 25 * a})
+        make_ideal(p)
+        psrs.append(p)
+    eng = ReplicaEngine(psrs, seed=3)
+    eng.set_white_noise(efac=1.1, log10_equad=-6.3)
+    eng.set_jitter(log10_ecorr=-6.5, coarsegrain=0.1)
+    eng.set_red_noise([-13.6, None, -14.0], [3.1, None, 4.2])
+    eng.set_gwb(-14.2, 13. / 3.)
+    eng.add_cgw(gwtheta=1.0, gwphi=2.0, mc=1e9, dist=20.0, fgw=2e-8, phase0=0.3, psi=0.4, inc=0.5, tref=53000 * 86400)
+    eng.prepare().prepare_td()
+    eng.td_draws = "registers"
+    ref = eng.generate_td(70, r0=5)
+    eng.td_draws = "memory"
+    got = eng.generate_td(70, r0=5)
+    assert torch.equal(got, ref)
+    assert torch.equal(eng.generate_td(9, r0=40), ref[35:44])
+    eng.td_draws = "registers"
+    assert torch.equal(eng.generate_td(70, r0=5), ref)
