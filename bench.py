@@ -275,11 +275,21 @@ def td_mode_numbers(eng, R):
     if uniform:
         n, ld, P = counts[0], eng.td_ld[0], eng.P
         info = dv.zeros((P,), dtype=torch.int32)
-        ts = []
+        # the schedule prepare_td() uses (workspace scheme, next panel's diagonal phase run ahead) and the workspace-free two-chain one
+        need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, _lib.POTRF_DIAG_AHEAD))
+        work = dv.empty((need,))
+        ts, ts_free = [], []
         for _ in range(2):
             ta = wall(assemble)
-            ts.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
+            ts.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD,
+                                             dv.ptr(work), need, s)))
+            bad = int(info.abs().sum().item())
+            wall(assemble)
+            ts_free.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
+            info.add_(bad)
+        del work
         tp = min(ts)
+        res.update({"potrf_workspace_GB": 8.0 * need / 1e9, "potrf_without_workspace_ms": min(ts_free) * 1e3})
         res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_GBps_lower_triangle": 8.0 * sum(n * (n + 64) / 2 for n in counts) / ta / 1e9,
                     "potrf_ms": tp * 1e3, "potrf_TFLOPs": flop_chol / tp / 1e12, "potrf_frac_of_fp64_mfma_peak": flop_chol / tp / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "positive_definite": int(info.abs().sum().item()) == 0})

@@ -321,6 +321,9 @@ struct pta_potrf_ctx {
   hipStream_t chain[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_in = nullptr, ev_out[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_diag[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // chain c's first diagonal phase is done
+  hipStream_t side[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};   // look-ahead stream of chain c (workspace scheme)
+  hipEvent_t ev_u1[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};   // the next panel's diagonal block has been updated
+  hipEvent_t ev_la[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};   // the next panel's diagonal phase (look-ahead) is done
 };
 static thread_local pta_potrf_ctx g_potrf_ctx[PTA_POTRF_MAX_DEVICES];
 
@@ -334,6 +337,9 @@ static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
       PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
       PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
       PTA_HIP(hipEventCreateWithFlags(&c.ev_diag[i], hipEventDisableTiming));
+      PTA_HIP(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
+      PTA_HIP(hipEventCreateWithFlags(&c.ev_u1[i], hipEventDisableTiming));
+      PTA_HIP(hipEventCreateWithFlags(&c.ev_la[i], hipEventDisableTiming));
     }
     PTA_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
     c.ready = true;
@@ -412,9 +418,12 @@ static int pta_potrf_step(double *A, int n, int64_t lda, int64_t strideA, int B,
 // the same panel becomes
 //   (1) the recursion on the nbo x nbo DIAGONAL block only (rows = nbo: a fifth of the work at n = 5000);
 //   (2) W_jj = (L11's 128 x 128 diagonal block j)^-1 for all j at once, from the 64 x 64 inverses k_potf2 parks (k_inv_blocks);
-//   (3) blocked substitution over the 128-column blocks, left to right, on ALL rows below, two tile products per block:
-//         B_j -= X_{<j} L11[j, <j]^T        (K = 128 j; X_{<j} are the finished blocks to the left)
-//         X_j  = B_j W_jj^T                 (K = 128; in place: one column tile per launch reads its columns before it writes them)
+//   (3) blocked substitution over the 128-column blocks, left to right, on ALL rows below.  Block j is X_j = (B_j - X_{<j} L11[j, <j]^T)
+//       W_jj^T = B_j W_jj^T - X_{<j} T_j^T with T_j = W_jj L11[j, <j] (128 x 128 j, a small product per matrix on the panel's own rows):
+//       the finished blocks X_{<j} and B_j are CONTIGUOUS columns of the rows below, so with the strip S_j = [-T_j | W_jj] kept in the
+//       workspace the block is ONE tile product X_j = [X_{<j} | B_j] S_j^T, K = 128 (j + 1) - 8 launches per panel instead of 15, none
+//       of them the K = 128 product that pays a full tile prologue and store for 128 columns of work (40 TFLOP/s against 57-61 at K >=
+//       512; in place: one column tile per launch reads its columns before it writes them);
 //   (4) the trailing update as before (K = nbo).
 // cond(L11's diagonal blocks) * eps enters X, as it already does through the 64 x 64 inverses: the TD covariances have cond(L) ~
 // 1e2-1e4, their factors agree with LAPACK to 1e-10 (tests); ill-conditioned inputs take PTA_POTRF_SUBSTITUTION (workspace ignored).
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
   const int wd = blk == 0 ? f128 : 128;                     // its width
   const int w1 = wd > 64 ? wd - 64 : wd, w2 = wd - w1;      // base blocks inside it (w2 = 64 or 0)
   const double *M = A + (int64_t)blockIdx.y * sA + (int64_t)(k0 + o) * lda + (k0 + o);
-  double *Wb = W + (int64_t)blockIdx.y * sW + (int64_t)blk * 128 * ldw;   // W_jj of block j at rows [128 j, 128 j + 128) of the workspace
+  double *Wb = W + (int64_t)blockIdx.y * sW + (int64_t)blk * 128 * ldw + o;  // strip j = rows [128 j, 128 j + 128) of the workspace: W_jj at its columns [o, o + 128)
   const int t = threadIdx.x;
   for (int idx = t; idx < 64 * 64; idx += 256) {
     const int r = idx >> 6, c = idx & 63;  // tile element (r, c), c fastest: coalesced
@@ -447,14 +456,31 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
     L21[r][c] = l;
   }
   __syncthreads();
+  // the off-diagonal block -X2 (L21 X1): two 64 x 64 x 64 products on the matrix cores, a wave per 16 rows, operands from LDS
+  const int l = t & 63, wv = t >> 6, li = l & 15, lq = l >> 4;
+  pta_f64x4 acc[4];
   if (w2) {
-    for (int idx = t; idx < 64 * 64; idx += 256) {  // T = L21 X1
-      const int r = idx >> 6, c = idx & 63;
-      double acc = 0.0;
-      for (int k = c; k < w1; ++k) acc = fma(L21[r][k], X1[k][c], acc);  // X1 lower triangular: k >= c
-      T[r][c] = acc;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = L21[16 * wv + li][k + lq];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, X1[k + lq][16 * cb + li], acc[cb]);
     }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[16 * wv + pta_mfma_row(l, r)][16 * cb + pta_mfma_col(l)] = acc[cb][r];
     __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = X2[16 * wv + li][k + lq];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, T[k + lq][16 * cb + li], acc[cb]);
+    }
   }
   for (int idx = t; idx < 128 * 128; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
@@ -462,68 +488,245 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
     if (r < wd && c < wd) {
       if (r < w1) v = c < w1 ? X1[r][c] : 0.0;
       else if (c >= w1) v = X2[r - w1][c - w1];
-      else {
-        double acc = 0.0;
-        for (int k = 0; k <= r - w1; ++k) acc = fma(X2[r - w1][k], T[k][c], acc);  // X2 lower triangular: k <= r
-        v = -acc;
-      }
+      else continue;                // the product block: written from the accumulators below
     }
     Wb[(int64_t)r * ldw + c] = v;   // the whole 128 x 128 slot is written (zeros outside the block): the products read K = 128 of it
   }
+  if (w2) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wv + pta_mfma_row(l, r), col = 16 * cb + pta_mfma_col(l);
+        if (col < w1) Wb[(int64_t)(w1 + row) * ldw + col] = -acc[cb][r];
+      }
+  }
 }
 
-#define PTA_POTRF_WS_LD 128   // leading dimension of the workspace: one 128 x 128 inverse per 128-column block of a panel
+// -T_j = -W_jj L11[j, <j] for every block j >= 1 of a panel in ONE launch (the strips' left parts): one workgroup per (group of four
+// 64-column chunks of a strip, matrix).  The 128 x 64 chunk of L11 goes through LDS (coalesced 16-byte loads, the next chunk in flight
+// in registers while this one is multiplied).  The k slot of lane group q at step t = 2 u + s is m = 8 u + 2 q + s, so a lane's A
+// elements are pairs of neighbours in its row of W_jj (16-byte loads, read ONCE and kept in registers for the chunks the workgroup
+// walks).  W_jj is lower triangular: the 16-row block b needs m < 16 (b + 1) only, i.e. its first 4 (b + 1) steps; a wave takes the
+// blocks w and 7 - w (36 of the 64 block-steps, the same for every wave).
+#define PTA_WS_STRIP_GROUP 4
+__global__ __launch_bounds__(256) void k_ws_strips(const double *__restrict__ A, int64_t lda, int64_t sA, int k0, int f128, double *__restrict__ W,
+                                                   int64_t ldw, int64_t sW) {
+  __shared__ double Bs[128][64];
+  int g = blockIdx.x, j = 1, oj = f128;
+  for (;;) {  // group -> (block j, group inside its chunks)
+    const int ng = (((oj + 63) >> 6) + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
+    if (g < ng) break;
+    g -= ng;
+    ++j;
+    oj += 128;
+  }
+  double *S = W + (int64_t)blockIdx.y * sW + (int64_t)j * 128 * ldw;
+  const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), c = l & 15, q = l >> 4;
+  typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // k0, oj may be odd: 8-byte alignment only
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const int nch = (oj + 63) >> 6, ch0 = g * PTA_WS_STRIP_GROUP, ch1 = min(nch, ch0 + PTA_WS_STRIP_GROUP);
+  // chunk rows oj .. oj + 127 of L11, columns c0 .. c0 + 63 (columns past oj are the block's own: valid memory, products not stored)
+  const double *Lrow = A + (int64_t)blockIdx.y * sA + (int64_t)(k0 + oj + (t >> 5)) * lda + k0 + 2 * (t & 31);
+  f64x2_a8 pre[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + 64 * ch0);
+  const int blo = w, bhi = 7 - w;                      // the wave's two 16-row blocks
+  const int ulo = 2 * (blo + 1), uhi = 2 * (bhi + 1);  // 8-column groups of W_jj they reach into
+  const double *alo = S + oj + (int64_t)(16 * blo + c) * ldw + 2 * q, *ahi = S + oj + (int64_t)(16 * bhi + c) * ldw + 2 * q;
+  f64x2_a8 xlo[8], xhi[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    xhi[u] = u < uhi ? *reinterpret_cast<const f64x2_a8 *>(ahi + 8 * u) : f64x2_a8{0.0, 0.0};
+    if (u < 8) xlo[u] = u < ulo ? *reinterpret_cast<const f64x2_a8 *>(alo + 8 * u) : f64x2_a8{0.0, 0.0};
+  }
+  for (int ch = ch0; ch < ch1; ++ch) {
+    const int c0 = 64 * ch;
+    if (ch > ch0) __syncthreads();  // every wave is done with the previous chunk
+#pragma unroll
+    for (int i = 0; i < 16; ++i) *reinterpret_cast<f64x2 *>(&Bs[8 * i + (t >> 5)][2 * (t & 31)]) = f64x2{pre[i].x, pre[i].y};
+    __syncthreads();
+    if (ch + 1 < ch1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + 64 * (ch + 1));
+    }
+    pta_f64x4 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    double bb[2][2][4];  // [u & 1]: the fragments of step u + 1 are read from LDS before the products of step u are issued
+#pragma unroll
+    for (int sft = 0; sft < 2; ++sft)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) bb[0][sft][cb] = Bs[2 * q + sft][16 * cb + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u < uhi) {  // wave-uniform
+        if (u + 1 < 16) {
+#pragma unroll
+          for (int sft = 0; sft < 2; ++sft)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bb[(u + 1) & 1][sft][cb] = Bs[8 * (u + 1) + 2 * q + sft][16 * cb + c];
+        }
+        // four independent accumulators between two products into the same one
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[1][cb] = pta_mfma_f64(xhi[u].x, bb[u & 1][0][cb], acc[1][cb]);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[1][cb] = pta_mfma_f64(xhi[u].y, bb[u & 1][1][cb], acc[1][cb]);
+        if (u < 8 && u < ulo) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[0][cb] = pta_mfma_f64(xlo[u < 8 ? u : 0].x, bb[u & 1][0][cb], acc[0][cb]);
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) acc[0][cb] = pta_mfma_f64(xlo[u < 8 ? u : 0].y, bb[u & 1][1][cb], acc[0][cb]);
+        }
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * (rb ? bhi : blo) + pta_mfma_row(l, r), col = c0 + 16 * cb + pta_mfma_col(l);
+          if (col < oj) S[(int64_t)row * ldw + col] = -acc[rb][cb][r];
+        }
+  }
+}
+
+// workspace of one matrix: one strip S_j = [-T_j | W_jj] of 128 rows per 128-column block of a panel, leading dimension = the widest
+// panel rounded up to whole blocks (NBO + 127 columns at most)
+static inline int64_t pta_potrf_ws_ld(int NBO) { return (int64_t)((NBO + 127 + 127) / 128) * 128; }
 
 extern "C" int64_t pta_potrf_workspace_doubles(int n, int B, int flags) {
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;
   if (n <= NBO || B <= 0 || (flags & (PTA_POTRF_VALU | PTA_POTRF_SUBSTITUTION))) return 0;
-  const int64_t nblk = (NBO + 127 + 127) / 128;  // the widest panel is NBO + 127 columns
-  return (int64_t)B * nblk * 128 * PTA_POTRF_WS_LD;
+  const int64_t ldw = pta_potrf_ws_ld(NBO);
+  return (int64_t)B * ldw * ldw;
+}
+
+// panel geometry of the workspace scheme
+struct pta_ws_panel {
+  int k0, nbo, pend, rows, nb, f128;
+};
+static inline pta_ws_panel pta_ws_panel_at(int n, int NBO, int k0) {
+  pta_ws_panel p;
+  p.k0 = k0;
+  const int want = (k0 == 0 && n > NBO) ? NBO + (n % 128) : NBO;
+  p.nbo = (n - k0 < want) ? (n - k0) : want;
+  p.pend = k0 + p.nbo;
+  p.rows = n - p.pend;
+  p.nb = (p.nbo + 127) / 128;
+  p.f128 = p.nbo - 128 * (p.nb - 1);  // first block narrower when nbo % 128 != 0
+  return p;
+}
+
+// (1) + (2): the panel's diagonal block - the recursion with the matrix "ending" at the panel's last row - the 128 x 128 inverses and
+// the strips S_j = [-W_jj L11[j, <j] | W_jj] the substitution multiplies by
+static int pta_ws_diag_phase(double *A, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, const pta_ws_panel &p, double *W,
+                             int64_t ldw, int64_t sW, hipStream_t s) {
+  int rc = pta_factor_panel(A, p.pend, lda, strideA, B, p.k0, p.nbo, info, flags, algo, s);
+  if (rc != PTA_OK) return rc;
+  if (p.rows <= 0) return PTA_OK;
+  hipLaunchKernelGGL(k_inv_blocks, dim3(p.nb, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.nbo, p.f128, W, ldw, sW);
+  PTA_LAUNCH_CHECK();
+  if (p.nb > 1) {
+    int groups = 0;
+    for (int j = 1; j < p.nb; ++j) groups += ((p.f128 + 128 * (j - 1) + 63) / 64 + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
+    hipLaunchKernelGGL(k_ws_strips, dim3(groups, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.f128, W, ldw, sW);
+    PTA_LAUNCH_CHECK();
+  }
+  return PTA_OK;
+}
+
+// (3): blocked substitution on the rows below, left to right: X_j = [X_{<j} | B_j] S_j^T
+static int pta_ws_solve_phase(double *A, int64_t lda, int64_t strideA, int B, int algo, const pta_ws_panel &p, double *W, int64_t ldw, int64_t sW,
+                              hipStream_t s) {
+  double *Bp = A + (int64_t)p.pend * lda + p.k0;
+  for (int j = 0; j < p.nb; ++j) {
+    const int oj = j == 0 ? 0 : p.f128 + 128 * (j - 1), wj = j == 0 ? p.f128 : 128;
+    const double *Sj = W + (int64_t)j * 128 * ldw;
+    // in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so a block the
+    // launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left (chunk [c0, c1) needs the
+    // block's columns [0, c1) only: W_jj is lower triangular)
+    const int tile = pta_dgemm_tile_n(p.rows, wj, oj + wj, algo);
+    for (int c1 = wj; c1 > 0; c1 -= tile) {
+      const int c0 = c1 > tile ? c1 - tile : 0;
+      int rc = pta_dgemm_launch(1, p.rows, c1 - c0, oj + c1, 1.0, Bp, lda, 1, Sj + (int64_t)c0 * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B, strideA, sW,
+                                strideA, algo, s);
+      if (rc != PTA_OK) return rc;
+    }
+  }
+  return PTA_OK;
 }
 
 // One step of a chain with the workspace scheme; returns the next panel's first column in *k0_io.
 static int pta_potrf_step_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, int *k0_io,
                              double *W, int64_t sW, hipStream_t s, hipEvent_t ev_after_diag) {
-  const int k0 = *k0_io;
-  const int want = (k0 == 0 && n > NBO) ? NBO + (n % 128) : NBO;
-  const int nbo = (n - k0 < want) ? (n - k0) : want;
-  const int pend = k0 + nbo;
-  // (1) the diagonal block: the recursion with the matrix "ending" at the panel's last row
-  int rc = pta_factor_panel(A, pend, lda, strideA, B, k0, nbo, info, flags, algo, s);
+  const pta_ws_panel p = pta_ws_panel_at(n, NBO, *k0_io);
+  const int64_t ldw = pta_potrf_ws_ld(NBO);
+  int rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, s);
   if (rc != PTA_OK) return rc;
-  *k0_io = pend;
-  const int rows = n - pend;
-  if (rows <= 0) return PTA_OK;
-  const int64_t ldw = PTA_POTRF_WS_LD;
-  // (2) the 128 x 128 inverses of the diagonal blocks
-  const int nb = (nbo + 127) / 128, f128 = nbo - 128 * (nb - 1);  // first block narrower when nbo % 128 != 0
-  hipLaunchKernelGGL(k_inv_blocks, dim3(nb, B), dim3(256), 0, s, A, lda, strideA, k0, nbo, f128, W, ldw, sW);
-  PTA_LAUNCH_CHECK();
+  *k0_io = p.pend;
+  if (p.rows <= 0) return PTA_OK;
   if (ev_after_diag) PTA_HIP(hipEventRecord(ev_after_diag, s));
-  // (3) blocked substitution on the rows below, left to right
-  const double *L11 = A + (int64_t)k0 * lda + k0;
-  double *Bp = A + (int64_t)pend * lda + k0;
-  for (int j = 0; j < nb; ++j) {
-    const int oj = j == 0 ? 0 : f128 + 128 * (j - 1), wj = j == 0 ? f128 : 128;
-    if (j > 0) {  // B_j -= X_{<j} L11[j, <j]^T
-      rc = pta_dgemm_launch(1, rows, wj, oj, -1.0, Bp, lda, 1, L11 + (int64_t)oj * lda, lda, 1.0, Bp + oj, lda, 0, B, strideA, strideA, strideA, algo, s);
-      if (rc != PTA_OK) return rc;
-    }
-    // X_j = B_j W_jj^T, in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so
-    // a block the launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left (chunk [c0, c1)
-    // needs the block's columns [0, c1) only: W_jj is lower triangular)
-    const int tile = pta_dgemm_tile_n(rows, wj, wj, algo);
-    for (int c1 = wj; c1 > 0; c1 -= tile) {
-      const int c0 = c1 > tile ? c1 - tile : 0;
-      rc = pta_dgemm_launch(1, rows, c1 - c0, c1, 1.0, Bp + oj, lda, 1, W + (int64_t)j * 128 * ldw + (int64_t)c0 * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B,
-                            strideA, sW, strideA, algo, s);
-      if (rc != PTA_OK) return rc;
-    }
-  }
+  if ((rc = pta_ws_solve_phase(A, lda, strideA, B, algo, p, W, ldw, sW, s)) != PTA_OK) return rc;
   // (4) trailing update
-  double *A22 = A + (int64_t)pend * lda + pend;
-  return pta_dgemm_launch(1, rows, rows, nbo, -1.0, Bp, lda, 1, Bp, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
+  double *Bp = A + (int64_t)p.pend * lda + p.k0;
+  double *A22 = A + (int64_t)p.pend * lda + p.pend;
+  return pta_dgemm_launch(1, p.rows, p.rows, p.nbo, -1.0, Bp, lda, 1, Bp, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
+}
+
+// A whole chain of the workspace scheme WITH LOOK-AHEAD (PTA_POTRF_DIAG_AHEAD): what separates two panels' tile products is the next
+// panel's diagonal phase - ~3.4 ms of pivot-by-pivot latency chains on a 1024 x 1024 block per step, during which the matrix cores idle.
+// It needs only that block of the trailing matrix, so the trailing update is issued in three pieces - U1 = the next panel's diagonal
+// block (36 tiles per matrix), then its sub-diagonal rectangle and the rest - and the next diagonal phase runs on a side stream as
+// soon as U1 is done, BESIDE the other two.  (Beside a tile product such kernels run ~3x slower - they share the fp64 ALUs - so the
+// look-ahead is only used while the rest of the update outlasts that: rows >= PTA_WS_LA_MIN_ROWS.)
+#define PTA_WS_LA_MIN_ROWS 1024
+static int pta_potrf_chain_ws_lookahead(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, double *W,
+                                        int64_t sW, hipStream_t s, hipStream_t side, hipEvent_t ev_u1, hipEvent_t ev_la) {
+  pta_ws_panel p = pta_ws_panel_at(n, NBO, 0);
+  const int64_t ldw = pta_potrf_ws_ld(NBO);
+  int rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, s);
+  if (rc != PTA_OK) return rc;
+  bool joined = true;  // false while a look-ahead diagonal phase is in flight on `side`
+  while (p.rows > 0) {
+    if ((rc = pta_ws_solve_phase(A, lda, strideA, B, algo, p, W, ldw, sW, s)) != PTA_OK) break;
+    const pta_ws_panel q = pta_ws_panel_at(n, NBO, p.pend);   // the next panel
+    double *Bp = A + (int64_t)p.pend * lda + p.k0;            // X: rows below panel p, its columns
+    double *A22 = A + (int64_t)p.pend * lda + p.pend;
+    // U1: the next panel's diagonal block
+    rc = pta_dgemm_launch(1, q.nbo, q.nbo, p.nbo, -1.0, Bp, lda, 1, Bp, lda, 1.0, A22, lda, 1, B, strideA, strideA, strideA, algo, s);
+    if (rc != PTA_OK) break;
+    const bool la = q.rows >= PTA_WS_LA_MIN_ROWS;
+    if (la) {
+      if ((rc = hipEventRecord(ev_u1, s)) != hipSuccess || (rc = hipStreamWaitEvent(side, ev_u1, 0)) != hipSuccess) { rc = PTA_E_HIP; break; }
+      joined = false;
+      rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, q, W, ldw, sW, side);
+      (void)hipEventRecord(ev_la, side);
+      if (rc != PTA_OK) break;
+    }
+    if (q.rows > 0) {
+      // U2: rows below the next panel - its sub-diagonal rectangle (what solve(q) will turn into X) and the lower triangle behind it
+      const double *Xlo = Bp + (int64_t)q.nbo * lda;
+      rc = pta_dgemm_launch(1, q.rows, q.nbo, p.nbo, -1.0, Xlo, lda, 1, Bp, lda, 1.0, A22 + (int64_t)q.nbo * lda, lda, 0, B, strideA, strideA, strideA, algo, s);
+      if (rc != PTA_OK) break;
+      rc = pta_dgemm_launch(1, q.rows, q.rows, p.nbo, -1.0, Xlo, lda, 1, Xlo, lda, 1.0, A22 + (int64_t)q.nbo * lda + q.nbo, lda, 1, B, strideA, strideA,
+                            strideA, algo, s);
+      if (rc != PTA_OK) break;
+    }
+    if (la) {
+      (void)hipStreamWaitEvent(s, ev_la, 0);
+      joined = true;
+    } else if ((rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, q, W, ldw, sW, s)) != PTA_OK) {
+      break;
+    }
+    p = q;
+  }
+  if (!joined) (void)hipStreamWaitEvent(s, ev_la, 0);  // error exit: the chain's stream never runs ahead of its side stream
+  return rc;
 }
 
 // Right-looking over panels of NB = 1024 columns; the trailing update of a panel is ONE product with K = NB over the
@@ -547,7 +750,8 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
-  if (nchain == 0) nchain = 2;
+  // default: two chains; ONE with PTA_POTRF_DIAG_AHEAD (what a second chain hides, the look-ahead hides already: 53.6 against 54.1 ms)
+  if (nchain == 0) nchain = (flags & PTA_POTRF_DIAG_AHEAD) ? 1 : 2;
   if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
   if (nchain > B) nchain = B;
   if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;
@@ -560,7 +764,26 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
                   : pta_potrf_step(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, st);
   };
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
-  if (nchain == 1) {
+  if (use_ws && (flags & PTA_POTRF_DIAG_AHEAD) && !(flags & PTA_POTRF_NO_LOOKAHEAD)) {
+    pta_potrf_ctx *cx = nullptr;
+    int rc = pta_potrf_ctx_get(&cx);
+    if (rc != PTA_OK) return rc;
+    PTA_HIP(hipEventRecord(cx->ev_in, s));
+    int rc_chain = PTA_OK;
+    for (int c = 0; c < nchain && rc_chain == PTA_OK; ++c) {
+      const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
+      hipStream_t sc = nchain == 1 ? s : cx->chain[c];
+      if (nchain > 1) PTA_HIP(hipStreamWaitEvent(sc, cx->ev_in, 0));
+      rc_chain = pta_potrf_chain_ws_lookahead(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, work + (int64_t)b0 * sWm, sWm,
+                                              sc, cx->side[c], cx->ev_u1[c], cx->ev_la[c]);
+    }
+    if (nchain > 1)
+      for (int c = 0; c < nchain; ++c) {
+        (void)hipEventRecord(cx->ev_out[c], cx->chain[c]);
+        (void)hipStreamWaitEvent(s, cx->ev_out[c], 0);
+      }
+    if (rc_chain != PTA_OK) return rc_chain;
+  } else if (nchain == 1) {
     for (int k0 = 0; k0 < n;) {
       int rc = chain_step(A, B, info, work, &k0, s, nullptr);
       if (rc != PTA_OK) return rc;

@@ -71,16 +71,19 @@ class TimeDomainMixin:
                   dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
         # batched factorisation: runs of consecutive pulsars with the same TOA count share one launch sequence
         info = dv.zeros((P,), dtype=torch.int32)
-        flags = 0 if lookahead else _lib.POTRF_NO_LOOKAHEAD
+        # workspace scheme of the factorisation (include/pta_replicator_amd.h: pta_potrf_batched_ws): strips [-W_jj L11[j, <j] | W_jj] of
+        # the panels' diagonal blocks, 10.6 MB per matrix at the default panel width, released right after the factorisation - and
+        # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.6 ms against 56.5 ms
+        # without; td_potrf_workspace = False keeps the workspace-free two-chain schedule.
+        use_ws = bool(getattr(self, "td_potrf_workspace", True))
+        flags = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
+        flags |= int(getattr(self, "td_potrf_flags", 0))
         a = 0
         while a < P:
             b = a
             while b + 1 < P and counts[b + 1] == counts[a]:
                 b += 1
-            # optional workspace of the inverse-based panel solves (include/pta_replicator_amd.h: pta_potrf_batched_ws; 11.8 MB per
-            # matrix, released right after the factorisation).  Off by default: measured 61 ms against 56 ms for the 68 x 5000^2
-            # batch - what it saves in K <= 512 products it loses in the latency chain of the diagonal phase
-            need = int(_lib.lib.pta_potrf_workspace_doubles(counts[a], b - a + 1, flags)) if getattr(self, "td_potrf_workspace", False) else 0
+            need = int(_lib.lib.pta_potrf_workspace_doubles(counts[a], b - a + 1, flags)) if use_ws else 0
             work = dv.empty((need,)) if need else None
             _lib.call("pta_potrf_batched_ws", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), counts[a], ld[a],
                       counts[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, dv.ptr(work), need, s)

@@ -9,6 +9,9 @@ look = sys.argv[3] != "0"
 psrs, noise = headline_array(P, N)
 eng = configure_engine(ReplicaEngine(psrs, seed=1), noise)
 eng._gw = None
-eng.td_potrf_workspace = len(sys.argv) > 4 and sys.argv[4] == "ws"
+eng.td_potrf_workspace = len(sys.argv) > 4 and sys.argv[4] in ("ws", "wsla")
+if len(sys.argv) > 4 and sys.argv[4] == "wsla":
+    from pta_replicator_amd import _lib
+    eng.td_potrf_flags = _lib.POTRF_DIAG_AHEAD
 eng.prepare_td(lookahead=look)
 torch.cuda.synchronize()

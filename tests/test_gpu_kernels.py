@@ -203,13 +203,16 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
 
 
 @pytest.mark.parametrize("n,batch,flags", [(1025, 2, 0), (1338, 3, 0), (2500, 2, 0), (2501, 1, 0), (700, 3, "NB1"), (1338, 3, "NB1"), (2500, 2, "NB1C3"),
-                                           (3000, 5, "C4")])
+                                           (3000, 5, "C4"), (3000, 2, "LA"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1")])
 def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
     over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
     orders (non-vector operand path), narrow panels (256 columns: many steps, first panel 256 + n % 128 wide) and 3 / 4 chains."""
     dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
-    fl = {0: 0, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3), "C4": lib.POTRF_CHAINS(4)}[flags]
+    fl = {0: 0, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3), "C4": lib.POTRF_CHAINS(4),
+          # look-ahead of the next panel's diagonal phase on a side stream (used while >= 1536 rows remain below it)
+          "LA": lib.POTRF_DIAG_AHEAD, "NB1LA": lib.POTRF_NB(1) | lib.POTRF_DIAG_AHEAD, "NB1C3LA": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3) | lib.POTRF_DIAG_AHEAD,
+          "NB2LA1": lib.POTRF_NB(2) | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(2)}[flags]
     rng = np.random.default_rng(n + batch)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
