@@ -159,14 +159,15 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 /* The same factorisation with a caller-owned workspace (device memory, `work_doubles` doubles, at least
- * pta_potrf_workspace_doubles(n, B, flags) - B * 9 * 128 * 128 doubles = 1.2 MB per matrix at the default panel width; 0 = the
- * workspace scheme does not apply: n <= panel width, or the VALU / SUBSTITUTION paths).  With it a panel is factored on its nbo x nbo
- * DIAGONAL block only, the 128 x 128 diagonal blocks of L11 are inverted into the workspace, and the rows below are solved by
- * blocked substitution - per 128 columns one update product (K up to the panel width) and one product with the inverted block -
- * instead of by the recursion over the panel's full height: no 64-column solves or K = 64 updates over all rows, fewer launches, and
- * what is left of the latency-bound kernels works on the diagonal block's few rows.  cond(diagonal blocks) * eps enters X, as it does
- * through the 64 x 64 inverses of pta_potrf_batched_ex; ill-conditioned matrices take PTA_POTRF_SUBSTITUTION (workspace ignored).
- * work == NULL or too small: identical to pta_potrf_batched_ex.                                                                */
+ * pta_potrf_workspace_doubles(n, B, flags) - B * 1152^2 doubles = 10.6 MB per matrix at the default panel width; 0 = the workspace
+ * scheme does not apply: n <= panel width, or the VALU / SUBSTITUTION paths).  With it a panel is factored on its nbo x nbo DIAGONAL
+ * block only, the 128 x 128 diagonal blocks of L11 are inverted (W_jj) and the strips S_j = [-W_jj L11[j, <j] | W_jj] go to the
+ * workspace, and the rows below are solved by blocked substitution - ONE tile product X_j = [X_{<j} | B_j] S_j^T per 128 columns,
+ * K = 128 (j + 1), in place - instead of by the recursion over the panel's full height: no 64-column solves or K = 64 updates over
+ * all rows, a quarter of the launches, and what is left of the latency-bound kernels works on the diagonal block's few rows.
+ * PTA_POTRF_DIAG_AHEAD additionally runs the next panel's diagonal phase on an internal side stream beside the trailing update.
+ * cond(diagonal blocks) * eps enters X, as it does through the 64 x 64 inverses of pta_potrf_batched_ex; ill-conditioned matrices
+ * take PTA_POTRF_SUBSTITUTION (workspace ignored).  work == NULL or too small: identical to pta_potrf_batched_ex.              */
 int64_t pta_potrf_workspace_doubles(int n, int B, int flags);
 int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
                          int64_t work_doubles, void *stream);
