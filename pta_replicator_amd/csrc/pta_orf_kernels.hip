@@ -679,11 +679,12 @@ static int pta_potrf_step_ws(double *A, int n, int64_t lda, int64_t strideA, int
 }
 
 // A whole chain of the workspace scheme WITH LOOK-AHEAD (PTA_POTRF_DIAG_AHEAD): what separates two panels' tile products is the next
-// panel's diagonal phase - ~3.4 ms of pivot-by-pivot latency chains on a 1024 x 1024 block per step, during which the matrix cores idle.
+// panel's diagonal phase - ~2.4 ms of pivot-by-pivot latency chains on a 1024 x 1024 block per step, during which the matrix cores idle.
 // It needs only that block of the trailing matrix, so the trailing update is issued in three pieces - U1 = the next panel's diagonal
 // block (36 tiles per matrix), then its sub-diagonal rectangle and the rest - and the next diagonal phase runs on a side stream as
-// soon as U1 is done, BESIDE the other two.  (Beside a tile product such kernels run ~3x slower - they share the fp64 ALUs - so the
-// look-ahead is only used while the rest of the update outlasts that: rows >= PTA_WS_LA_MIN_ROWS.)
+// soon as U1 is done, BESIDE the other two.  (Beside a tile product such kernels run ~7x slower - a dependent fp64 chain waits out the
+// 64-cycle MFMA blocks of the waves it shares a SIMD with: 17.9 ms for the phase that takes 2.4 alone - so the look-ahead is only
+// used while the rest of the update is long: rows >= PTA_WS_LA_MIN_ROWS below the next panel; 512 / 1024 / 1536 measured the same.)
 #define PTA_WS_LA_MIN_ROWS 1024
 static int pta_potrf_chain_ws_lookahead(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, double *W,
                                         int64_t sW, hipStream_t s, hipStream_t side, hipEvent_t ev_u1, hipEvent_t ev_la) {
