@@ -172,8 +172,8 @@ def api_mode_timing(psrs, noise, repeats=2):
     """ONE realisation of the bench array through the drop-in add_* API (replay mode: NumPy legacy draws on the host in the
     reference's order, host-owned pulsar objects, PCIe both ways), in ms: `loop` = the reference's usage, one call per pulsar and
     signal (tests/test_against_libstempo.py:25-53, notebook cell 9); `list` = the same calls given the pulsar list (one launch per
-    signal, per-pulsar legacy streams drawn on host threads).  `host_rng_ms` = what np.random alone costs for these draws on this
-    host, single thread - the floor of the loop form."""
+    signal, the pulsars' legacy streams drawn by the native restatement of NumPy's generator on host threads - pta_legacy_randn).
+    `host_rng_ms` = what np.random alone costs for these draws on this host, single thread - the floor of the loop form."""
     import torch
     from pta_replicator_amd.simulate import make_ideal
     from pta_replicator_amd.white_noise import add_measurement_noise, add_jitter

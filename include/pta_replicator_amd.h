@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 3
+#define PTA_ABI_VERSION 4
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -101,6 +101,14 @@ int pta_dot3_host(const double *x_host, int64_t n, const double *y_host, double 
 /* out_host[i] = pow(x_host[i], y) through libm's scalar pow (what the reference's per-source scalar expressions evaluate to;
  * NumPy's array power differs from it by an ulp on a few per cent of arguments).                                        */
 int pta_pow_host(const double *x_host, double y, int64_t n, double *out_host);
+/* HOST helper of replay mode: NumPy's LEGACY normal stream, stream i = np.random.RandomState(seeds_host[i]).randn(counts_host[i])
+ * value for value (MT19937 by init_genrand, 53-bit doubles, polar method with the cached second deviate: what np.random.seed(seed);
+ * np.random.randn(n) of white_noise.py:79-80,105-109,154-155,182 and red_noise.py:112-113,127 yields), written to out_host +
+ * offsets_host[i]; the streams are drawn on n_threads host threads (0 = one per core, at most 16).  The state the LAST stream is left in comes back
+ * in last_key_host [624], last_pos_has_host [2] = (pos, has_gauss), last_gauss_host [1] (any NULL: not wanted) - the caller installs it
+ * with np.random.set_state so that the global stream continues as after the reference's sequential calls.                       */
+int pta_legacy_randn(const uint32_t *seeds_host, const int64_t *counts_host, const int64_t *offsets_host, int n_streams,
+                     double *out_host, uint32_t *last_key_host, int32_t *last_pos_has_host, double *last_gauss_host, int n_threads);
 
 /* out[r,i] (+)= ecorr_epoch[epoch_of[i]] * z[r*ld_z + epoch_of[i]]
  * Replaces dt = (U*ecorrvec) @ randn(E) (white_noise.py:182): a gather, not an N x E matvec. */

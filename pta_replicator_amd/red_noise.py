@@ -123,12 +123,9 @@ def _add_red_noise_list(psrs, log10_amplitude, spectral_index, components, seed,
     if seeds is None:
         ys = [amp * np.random.randn(amp.size) for (_, _, amp) in inp]
     else:   # every pulsar re-seeds: its 2 * components draws are the head of the stream np.random.seed(seed_a) starts
-        ys = []
-        for a, (_, _, amp) in zip(live, inp):
-            rs = np.random.RandomState(seeds[a])
-            ys.append(amp * rs.randn(amp.size))
-        if live:
-            np.random.set_state(rs.get_state())
+        from .white_noise import _legacy_normals  # native restatement of the legacy stream, the pulsars' streams on host threads
+        zs = _legacy_normals([seeds[a] for a in live], [[amp.size] for (_, _, amp) in inp]) if live else []
+        ys = [amp * z[0] for (_, _, amp), z in zip(inp, zs)]
     counts = [len(t) for (t, _, _) in inp]
     off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     dev = dv.upload_packed([np.concatenate([t for (t, _, _) in inp])] + [x for (_, f, _) in inp for x in (f,)] + ys) if live else []
@@ -255,27 +252,25 @@ def add_gwb(psrs, log10_amplitude, spectral_index, no_correlations=False, seed=N
 
     ldt = pad16(npts)
     T = dv.empty((2 * (Nf - 2), ldt))
-    sqrtC = dv.f64(C ** 0.5)
+    # every operand of the call in ONE pinned staging copy (device.upload_packed), the result in one
+    toa_s = [psr.toas.get_mjds().value.astype(float) * 86400 for psr in psrs]
+    counts = [len(t) for t in toa_s]
+    ntot = int(np.sum(counts))
+    sqrtC, w_d, toa_d, ut_d, psr_of = dv.upload_packed([C ** 0.5, w, np.concatenate(toa_s), grid["ut"],
+                                                        np.repeat(np.arange(Npulsars, dtype=np.int32), counts)])
     s = dv.stream_ptr()
     _lib.call("pta_gwb_twiddle", dv.ptr(sqrtC), Nf, npts, 10, ctypes.c_double(1.0 / dt), dv.ptr(T), ldt, s)
-    w_d = dv.f64(w)
     G0 = dv.empty((Npulsars, npts))
     _lib.call("pta_gwb_idft", dv.ptr(w_d), 2 * Nf, Npulsars, Nf, dv.ptr(T), ldt, npts, dv.ptr(G0), npts, 1, s)
     G = dv.empty((Npulsars, npts))
     _lib.call("pta_gwb_mix", dv.ptr(M), Npulsars, dv.ptr(G0), 1, npts, npts, dv.ptr(G), 0, s)
 
-    toa_s = [psr.toas.get_mjds().value.astype(float) * 86400 for psr in psrs]
-    counts = [len(t) for t in toa_s]
-    toa_d = dv.f64(np.concatenate(toa_s))
-    psr_of = dv.i32(np.repeat(np.arange(Npulsars), counts))
-    ntot = int(np.sum(counts))
-    ut_d = dv.f64(grid["ut"])
     jlo = dv.empty((ntot,), dtype=torch.int32)
     _lib.call("pta_gwb_bracket", dv.ptr(ut_d), npts, dv.ptr(toa_d), ntot, dv.ptr(jlo), s)
     out = dv.empty((1, ntot))
     _lib.call("pta_gwb_interp", dv.ptr(G), npts, Npulsars, npts, dv.ptr(ut_d), dv.ptr(toa_d), dv.ptr(psr_of), dv.ptr(jlo),
               ntot, 1, ctypes.c_double(1.0), dv.ptr(out), ntot, 0, s)
-    res_all = out[0].cpu().numpy()
+    res_all = dv.download(out[0])
     res_gw = np.split(res_all, np.cumsum(counts)[:-1])
 
     ct = 0

@@ -365,3 +365,43 @@ def test_write_partim_round_trip_for_array_backed_pulsars(tmp_path):
         assert M.shape == (400, m) and len(names) == m and np.linalg.matrix_rank(M) == m and np.max(np.abs(M)) <= 1.0 + 1e-12
     with pytest.raises(ValueError):
         timing_design_matrix(t, model="binary")
+
+
+def test_native_legacy_normal_stream_equals_numpy_value_for_value():
+    """pta_legacy_randn restates NumPy's legacy generator (MT19937 by init_genrand, 53-bit doubles, polar
+    method with the cached second deviate): every deviate bit-identical to RandomState(seed).randn, for seeds at both ends of the
+    32-bit range, odd counts (the cached deviate is carried from one randn call into the next), empty draws - and the GLOBAL stream
+    is left exactly where the reference's sequential np.random.seed / randn calls (white_noise.py:79-80,105-109,154-155,182;
+    red_noise.py:112-113,127,238-240) would leave it."""
+    from pta_replicator_amd.white_noise import _legacy_normals
+    seeds = [0, 1, 12345, 2 ** 32 - 1, 987654321, np.int64(77)]
+    counts = [[7, 3], [1], [5000, 5001], [0, 2], [101], [3, 3, 3]]
+    z = _legacy_normals(seeds, counts)
+    after = np.random.randn(5)
+    for sd, cs, zz in zip(seeds, counts, z):
+        rs = np.random.RandomState(int(sd))
+        for c, arr in zip(cs, zz):
+            assert np.array_equal(rs.randn(c), arr), (sd, c)
+    assert np.array_equal(after, rs.randn(5))            # the global stream continues from the last pulsar's state
+    # seeds NumPy accepts but the native path does not (a sequence): RandomState path, same contract
+    z2 = _legacy_normals([[1, 2, 3], 5], [[4], [4]])
+    assert np.array_equal(z2[0][0], np.random.RandomState([1, 2, 3]).randn(4)) and np.array_equal(z2[1][0], np.random.RandomState(5).randn(4))
+    np.random.seed(3)
+    z3 = _legacy_normals(None, [[2000, 2001], [1500]])   # seed=None: ONE stream through the pulsars in order
+    t3 = np.random.randn(3)
+    np.random.seed(3)
+    r3 = [[np.random.randn(2000), np.random.randn(2001)], [np.random.randn(1500)]]
+    assert all(np.array_equal(a, b) for zz, rr in zip(z3, r3) for a, b in zip(zz, rr)) and np.array_equal(t3, np.random.randn(3))
+    # thread count does not matter
+    from pta_replicator_amd import _lib
+    n = 9
+    tot = np.full(n, 777, dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(tot)]).astype(np.int64)
+    sd = np.arange(100, 100 + n, dtype=np.uint32)
+    outs = []
+    for nt in (1, 3, 16):
+        flat = np.empty(int(off[-1]))
+        _lib.call("pta_legacy_randn", sd.ctypes.data, tot.ctypes.data, off.ctypes.data, n, flat.ctypes.data, None, None, None, nt)
+        outs.append(flat)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0][:777], np.random.RandomState(100).randn(777))
