@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 4
+#define PTA_ABI_VERSION 5
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -65,6 +65,11 @@ int pta_rng_philox_raw(const uint32_t *ctr, const uint32_t *key, int n, uint32_t
  * for pairs p in [0, npairs), realisations r0 .. r0+R-1.                                   */
 int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t stream_id, int npairs, int interleave,
                         double *z0, double *z1, int64_t ld, int rng_fast, void *stream);
+/* The same fill for all blocks of a pta_td_plan in ONE launch: z[r * ld + blk_zoff[b] + j] = deviate j of stream (stream_kind, b),
+ * j < blk_n[b] rounded up to even (pairs are written whole), r < R.  blk_n / blk_zoff: device arrays (blk_zoff even), max_n = the
+ * largest blk_n; ld even, z 16-byte aligned.                                                                                    */
+int pta_rng_fill_normal_blocks(uint64_t seed, uint64_t r0, int R, uint32_t stream_kind, int n_blocks, const int32_t *blk_n,
+                               const int32_t *blk_zoff, int max_n, double *z, int64_t ld, int rng_fast, void *stream);
 
 /* ---------------------------------------------------------------- red noise -------- */
 /* Fourier design matrix, transposed: Ft[c*N + i] = column c of F for TOA i.

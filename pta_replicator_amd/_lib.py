@@ -66,6 +66,7 @@ _SIGNATURES = {
     "pta_device_info": (c_int, [POINTER(c_int), POINTER(c_int), c_char_p, c_int]),
     "pta_rng_philox_raw": (c_int, [_P, _P, c_int, _P, _P]),
     "pta_rng_fill_normal": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, c_int, _P, _P, c_int64, c_int, _P]),
+    "pta_rng_fill_normal_blocks": (c_int, [c_uint64, c_uint64, c_int, c_uint32, c_int, _P, _P, c_int, _P, c_int64, c_int, _P]),
     "pta_rn_basis": (c_int, [_P, c_int, c_double, _P, _P, c_int, c_int, _P, c_int64, _P]),
     "pta_rn_synth": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_wn": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
@@ -133,7 +134,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.pta_abi_version() != 4:
+if lib.pta_abi_version() != 5:
     raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
 
 

@@ -503,6 +503,10 @@ extern "C" int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint
   if (p.z) {
     PTA_REQUIRE(p.rows_per_real == 1 && p.ld_z >= 4 && p.blk_zoff, PTA_E_ARG,
                 "pta_td_trmm_rng: supplied deviates (plan.z) need rows_per_real == 1, blk_zoff and ld_z");
+    // (measured and not kept: the same product as a 128 x 128-tile GEMM with BOTH operands by LDS DMA - the tile kernel of
+    // pta_gemm.hip with a triangular K range, masked diagonal slabs and this epilogue, 4 x 4 fragments per wave instead of 1 x 16:
+    // 28.8-29.0 ms per 1024 realisations of the 68 x 5000 array against 29.0 for this kernel - the DMA slab pipeline bounds both at
+    // ~62 TFLOP/s executed - and a different summation order, i.e. no longer bit-identical to the register form)
     hipLaunchKernelGGL((k_td_trmm_rng<false, true>), dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);
   } else if (p.rng_fast)
     hipLaunchKernelGGL((k_td_trmm_rng<true, false>), dim3((unsigned)nwg), dim3(256), 0, pta_stream(stream), p, seed, r0, M, out, ld_out);

@@ -172,7 +172,6 @@ class TimeDomainMixin:
             if ws is None or ws[0].shape[0] < chunk:
                 ws = self._td_ws = (dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts)))
             tp.gw_G = ws[1].data_ptr()
-        from .engine import stream_id
         # "memory" (default): the deviates of a batch are written once (pta_rng_fill_normal, 8 bytes each: 2.8 GB per 1024 realisations of
         # the 68 x 5000 array) and READ by the product; "registers": generated inside the product's loop (no buffer) - the same numbers,
         # bit-identical realisations; 31.2 against 35.0 ms per 1024 (the fp64 Box-Muller shares the double-precision ALUs with the MFMAs)
@@ -192,11 +191,9 @@ class TimeDomainMixin:
             if npts:
                 _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(ws[0]), npts, s)
                 _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), int(self.mix_variant), s)
-            if zmem:
-                for a in range(P):
-                    na = int(self.counts[a])
-                    _lib.call("pta_rng_fill_normal", self.seed, r0 + lo, n, stream_id(STREAM_TD, a), (na + 1) // 2, 1,
-                              ctypes.c_void_p(zb.data_ptr() + 8 * int(zoff[a])), None, zb.stride(0), int(self.rng_fast), s)
+            if zmem:   # every pulsar's deviates of this chunk in one launch (stream (STREAM_TD, pulsar), as the register form draws them)
+                _lib.call("pta_rng_fill_normal_blocks", self.seed, r0 + lo, n, STREAM_TD, P, dv.ptr(self._td_layout[2]), dv.ptr(self._td_zoff),
+                          int(max(self.counts)), dv.ptr(zb), zb.stride(0), int(self.rng_fast), s)
             _lib.call("pta_td_trmm_rng", ctypes.byref(tp), self.seed, r0 + lo, n, ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)),
                       out.stride(0), s)
         return out
