@@ -166,8 +166,9 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 #define PTA_POTRF_REG_STAGING 32  /* A/B: the 128 x 128-tile updates stage their operand slabs through registers (pta_dgemm algo 1)
                                      instead of by LDS DMA (global_load_lds_dwordx4, pta_dgemm algo 2 - the default) */
 #define PTA_POTRF_DIAG_AHEAD 128   /* workspace scheme: the next panel's diagonal phase runs on an internal side stream as soon as its
-                                     block of the trailing update is done, beside the rest of that update (one chain unless
-                                     PTA_POTRF_CHAINS says otherwise) */
+                                     block of the trailing update is done, beside the rest of that update */
+#define PTA_POTRF_DIAG64 16         /* A/B (workspace scheme): the panel's diagonal block by the 64-column recursion (k_potf2 / k_trsm_mfma /
+                                     k_syrk64) + one inversion pass instead of the 128-column base case k_diag128 */
 #define PTA_POTRF_LOCKSTEP 64       /* A/B (workspace scheme): all chains start together instead of one diagonal phase apart */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 

@@ -81,28 +81,9 @@ extern "C" int pta_orf_combine(const double *basis, const double *clm, int nbasi
 // and column j itself is scaled by r.  The owners of column j publish it (unscaled) through a double-buffered LDS vector:
 // ONE barrier per step, no serial section.  The tile leaves as the MFMA panel solve wants it (L below, X^T above; X's
 // diagonal 1 / L[j][j] is recomputed by the consumer).
-__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n, int64_t sA, int k0, int nb, int32_t *__restrict__ info) {
-  __shared__ double colbuf[2][CH_NB];
-  double *M = A + (int64_t)blockIdx.x * sA + (int64_t)k0 * n + k0;  // n = row pitch (lda)
-  const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
-  double v[4][4];
-  // all 16 loads first, unconditional, from clamped addresses; the selects follow (predicated, or consumed one by one, each load
-  // is waited for on its own: 16 serial round trips at the head of a kernel that runs one workgroup per matrix)
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int pc = min(ti + 16 * a, nb - 1);
-      v[a][b] = M[(int64_t)pc * n + min(tc + 16 * b, pc)];
-    }
-  asm volatile("" ::: "memory");  // keep the loads together: nothing below may be scheduled between them
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int p = ti + 16 * a, q = tc + 16 * b;
-      v[a][b] = (p < nb && q <= p) ? v[a][b] : 0.0;
-    }
+// The 64-step sweep of k_potf2 on a tile held in the registers of 256 threads (v[a][b] = element (ti + 16 a, tc + 16 b); lower
+// triangle + diagonal loaded, zeros above); colbuf = the workgroup's double-buffered pivot column.  Shared with k_diag128.
+__device__ __forceinline__ void pta_potf2_sweep(double (&v)[4][4], double (*colbuf)[CH_NB], int nb, int ti, int tc, int32_t *info_b, int col0) {
 #pragma unroll
   for (int jq = 0; jq < 4; ++jq) {
     for (int jr = 0; jr < 16; ++jr) {
@@ -137,13 +118,38 @@ __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n
             if (p != j)
               v[a][b] = cp[a];        // column j scaled
             else {
-              if (!(d > 0.0) && info[blockIdx.x] == 0) info[blockIdx.x] = k0 + j + 1;  // LAPACK: leading minor j+1 not PD
+              if (!(d > 0.0) && *info_b == 0) *info_b = col0 + j + 1;  // LAPACK: leading minor j+1 not PD
               v[a][b] = d * r;        // L[j][j] = sqrt(d)
             }
           }
         }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n, int64_t sA, int k0, int nb, int32_t *__restrict__ info) {
+  __shared__ double colbuf[2][CH_NB];
+  double *M = A + (int64_t)blockIdx.x * sA + (int64_t)k0 * n + k0;  // n = row pitch (lda)
+  const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
+  double v[4][4];
+  // all 16 loads first, unconditional, from clamped addresses; the selects follow (predicated, or consumed one by one, each load
+  // is waited for on its own: 16 serial round trips at the head of a kernel that runs one workgroup per matrix)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pc = min(ti + 16 * a, nb - 1);
+      v[a][b] = M[(int64_t)pc * n + min(tc + 16 * b, pc)];
+    }
+  asm volatile("" ::: "memory");  // keep the loads together: nothing below may be scheduled between them
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int p = ti + 16 * a, q = tc + 16 * b;
+      v[a][b] = (p < nb && q <= p) ? v[a][b] : 0.0;
+    }
+  pta_potf2_sweep(v, colbuf, nb, ti, tc, info + blockIdx.x, k0);
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -503,6 +509,170 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
   }
 }
 
+// The base case of the workspace scheme's recursion: ONE workgroup per matrix factors a whole 128-column diagonal block (wd <= 128
+// columns at (c0, c0): a first part of w1 = wd - 64 (or wd) and a second of 64) AND writes its inverse W = [[X1, 0], [-X2 L21 X1, X2]]
+// into the block's 128 x 128 workspace slot - what took k_potf2 + k_trsm_mfma + k_syrk64 + k_potf2 (four dependent launches over
+// the rows of the block) and a share of k_inv_blocks: the two 64-step sweeps stay (registers of 256 threads, one barrier per pivot),
+// what lies between them - L21 = A21 X1^T, A22 -= L21 L21^T, the inverse's off-diagonal block - is 64 x 64 x 64 products on the
+// matrix cores out of LDS.  The tiles leave as k_potf2 leaves them (L below the diagonal, X^T parked above it).
+__global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t lda, int64_t sA, int c0, int wd, double *__restrict__ W,
+                                                 int64_t ldw, int64_t sW, int32_t *__restrict__ info) {
+  __shared__ double T11[64][65], T21[64][65], T22[64][65], TT[64][65];
+  __shared__ double colbuf[2][CH_NB];
+  const int w1 = wd > 64 ? wd - 64 : wd, w2 = wd - w1;
+  double *M = A + (int64_t)blockIdx.x * sA + (int64_t)c0 * lda + c0;
+  double *Wb = W + (int64_t)blockIdx.x * sW;  // the block's slot (the caller passes W already offset to strip j, column oj)
+  const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
+  const int l = t & 63, wv = t >> 6, li = l & 15, lq = l >> 4;
+  double v[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pc = min(ti + 16 * a, w1 - 1);
+      v[a][b] = M[(int64_t)pc * lda + min(tc + 16 * b, pc)];
+    }
+  if (w2) {  // the other two tiles: ALL their loads requested behind the first one's (unconditional, clamped), then into LDS along their rows
+    const double *M2 = M + (int64_t)w1 * lda;
+    const int c = t & 63, r0 = t >> 6;
+    double x21[16], x22[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + 4 * i;
+      x21[i] = M2[(int64_t)r * lda + min(c, w1 - 1)];
+      x22[i] = M2[(int64_t)r * lda + w1 + min(c, r)];
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + 4 * i;
+      T21[r][c] = c < w1 ? x21[i] : 0.0;
+      T22[r][c] = c <= r ? x22[i] : 0.0;
+    }
+  }
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int p = ti + 16 * a, q = tc + 16 * b;
+      v[a][b] = (p < w1 && q <= p) ? v[a][b] : 0.0;
+    }
+  pta_potf2_sweep(v, colbuf, w1, ti, tc, info + blockIdx.x, c0);
+  // tile 1 -> global as it is (L, X1^T parked above the diagonal) and -> LDS as XS[k][c] = X1[c][k]: the part above the diagonal
+  // as it is, 1 / L on the diagonal, zero below
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int p = ti + 16 * a, q = tc + 16 * b;
+      if (p < w1 && q < w1) M[(int64_t)p * lda + q] = v[a][b];
+      T11[p][q] = (p < w1 && q < w1) ? (q > p ? v[a][b] : (q == p ? 1.0 / v[a][b] : 0.0)) : 0.0;
+    }
+  __syncthreads();
+  pta_f64x4 acc[4];
+  if (w2) {
+    // L21 = A21 X1^T: a wave per 16 rows, in place (a wave reads and writes its own rows only)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = T21[16 * wv + li][k + lq];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, T11[k + lq][16 * cb + li], acc[cb]);
+    }
+    __syncthreads();  // (every lane of every wave has its A21 operands before rows are overwritten)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T21[16 * wv + pta_mfma_row(l, r)][16 * cb + pta_mfma_col(l)] = acc[cb][r];
+    __syncthreads();
+    // A22 -= L21 L21^T (the lower triangle is what the second sweep reads)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = T21[16 * wv + li][k + lq];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, T21[16 * cb + li][k + lq], acc[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T22[16 * wv + pta_mfma_row(l, r)][16 * cb + pta_mfma_col(l)] -= acc[cb][r];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int p = ti + 16 * a, q = tc + 16 * b;
+        v[a][b] = q <= p ? T22[p][q] : 0.0;
+      }
+    __syncthreads();  // colbuf: the first sweep's last column has been read by everybody
+    pta_potf2_sweep(v, colbuf, 64, ti, tc, info + blockIdx.x, c0 + w1);
+    double *M2 = M + (int64_t)w1 * lda;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int p = ti + 16 * a, q = tc + 16 * b;
+        M2[(int64_t)p * lda + w1 + q] = v[a][b];
+        T22[p][q] = q > p ? v[a][b] : (q == p ? 1.0 / v[a][b] : 0.0);  // XS2[k][c] = X2[c][k]
+      }
+    for (int idx = t; idx < 64 * 64; idx += 256) {  // L21 -> global (coalesced)
+      const int r = idx >> 6, c = idx & 63;
+      if (c < w1) M2[(int64_t)r * lda + c] = T21[r][c];
+    }
+    __syncthreads();
+    // TT = L21 X1 (X1[k][c] = T11[c][k]), then W21 = -X2 TT (X2[r][k] = T22[k][r])
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = T21[16 * wv + li][k + lq];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, T11[16 * cb + li][k + lq], acc[cb]);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) TT[16 * wv + pta_mfma_row(l, r)][16 * cb + pta_mfma_col(l)] = acc[cb][r];
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = 0; k < 64; k += 4) {
+      const double a = T22[k + lq][16 * wv + li];
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) acc[cb] = pta_mfma_f64(a, TT[k + lq][16 * cb + li], acc[cb]);
+    }
+  }
+  // the inverse -> the block's whole 128 x 128 workspace slot (zeros outside the block: the products read K = 128 of it); the
+  // off-diagonal product block comes from the accumulators below
+  {
+    const int c = t & 127, rh = t >> 7;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) {
+      const int r = rh + 2 * i;
+      double x = 0.0;
+      if (r < w1)
+        x = c < w1 ? T11[c][r] : 0.0;
+      else if (r < wd && c >= w1 && c < wd)
+        x = T22[c - w1][r - w1];
+      if (!(w2 && r >= w1 && r < wd && c < w1)) Wb[(int64_t)r * ldw + c] = x;
+    }
+  }
+  if (w2) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wv + pta_mfma_row(l, r), col = 16 * cb + pta_mfma_col(l);
+        if (col < w1) Wb[(int64_t)(w1 + row) * ldw + col] = -acc[cb][r];
+      }
+  }
+}
+
 // -T_j = -W_jj L11[j, <j] for every block j >= 1 of a panel in ONE launch (the strips' left parts): one workgroup per (group of four
 // 64-column chunks of a strip, matrix).  The 128 x 64 chunk of L11 goes through LDS (coalesced 16-byte loads, the next chunk in flight
 // in registers while this one is multiplied).  The k slot of lane group q at step t = 2 u + s is m = 8 u + 2 q + s, so a lane's A
@@ -622,15 +792,64 @@ static inline pta_ws_panel pta_ws_panel_at(int n, int NBO, int k0) {
   return p;
 }
 
-// (1) + (2): the panel's diagonal block - the recursion with the matrix "ending" at the panel's last row - the 128 x 128 inverses and
-// the strips S_j = [-W_jj L11[j, <j] | W_jj] the substitution multiplies by
+// X <- X W^T in place for `rows` rows of `wj` columns (W = a lower-triangular wj x wj block of the workspace): a launch must cover
+// ONE column tile (a second tile would read columns the first one is overwriting), so a block the launcher would split (few rows or
+// a narrow block: 64-wide tiles) goes chunk by chunk, right to left (chunk [c0, c1) needs the block's columns [0, c1) only).
+// `Xl` / `kl` > 0 prepend kl columns to the K range (the merged substitution: [X_{<j} | B_j] S_j^T, Sl = the strip's left part).
+static int pta_ws_apply_block(double *X, int64_t lda, int64_t strideA, int B, int rows, int wj, int kl, const double *S, int64_t ldw,
+                              int64_t sW, int algo, hipStream_t s) {
+  const int tile = pta_dgemm_tile_n(rows, wj, kl + wj, algo);
+  for (int c1 = wj; c1 > 0; c1 -= tile) {
+    const int c0 = c1 > tile ? c1 - tile : 0;
+    int rc = pta_dgemm_launch(1, rows, c1 - c0, kl + c1, 1.0, X - kl, lda, 1, S + (int64_t)c0 * ldw, ldw, 0.0, X + c0, lda, 0, B, strideA, sW,
+                              strideA, algo, s);
+    if (rc != PTA_OK) return rc;
+  }
+  return PTA_OK;
+}
+
+// The recursion of pta_factor_panel on the panel's DIAGONAL block (rows up to `pend`), with the 128-column group as its base case:
+// k_diag128 factors the group's diagonal block and writes its inverse W_jj to the workspace, the rows below (inside the diagonal
+// block) are one product with W_jj - no 64-column solves, K = 64 updates or separate inversion pass.
+static int pta_factor_diag_ws(double *A, int pend, int64_t lda, int64_t sA, int B, int c0, int w, int32_t *info, int algo, const pta_ws_panel &p,
+                              double *W, int64_t ldw, int64_t sW, hipStream_t sp) {
+  if (w <= 128) {
+    const int oj = c0 - p.k0;                                   // offset inside the panel: 0 for the first block, f128 + 128 (j - 1) after
+    const int j = oj == 0 ? 0 : (oj - p.f128) / 128 + 1;
+    double *Wjj = W + (int64_t)j * 128 * ldw + oj;
+    hipLaunchKernelGGL(k_diag128, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, Wjj, ldw, sW, info);
+    PTA_LAUNCH_CHECK();
+    const int rows = pend - c0 - w;
+    if (rows <= 0) return PTA_OK;
+    return pta_ws_apply_block(A + (int64_t)(c0 + w) * lda + c0, lda, sA, B, rows, w, 0, Wjj, ldw, sW, algo, sp);
+  }
+  int cols = (w / 2 / 128) * 128;  // right part: a multiple of 128; the left part takes the remainder (the first panel's n mod 128)
+  if (cols < 128) cols = 128;
+  const int w1 = w - cols;
+  int rc = pta_factor_diag_ws(A, pend, lda, sA, B, c0, w1, info, algo, p, W, ldw, sW, sp);
+  if (rc != PTA_OK) return rc;
+  const int rows = pend - (c0 + w1);
+  const double *L21 = A + (int64_t)(c0 + w1) * lda + c0;
+  double *A22 = A + (int64_t)(c0 + w1) * lda + (c0 + w1);
+  rc = pta_dgemm_launch(1, rows, cols, w1, -1.0, L21, lda, 1, L21, lda, 1.0, A22, lda, 1, B, sA, sA, sA, algo, sp);
+  if (rc != PTA_OK) return rc;
+  return pta_factor_diag_ws(A, pend, lda, sA, B, c0 + w1, cols, info, algo, p, W, ldw, sW, sp);
+}
+
+// (1) + (2): the panel's diagonal block, the 128 x 128 inverses W_jj and the strips S_j = [-W_jj L11[j, <j] | W_jj] the substitution
+// multiplies by
 static int pta_ws_diag_phase(double *A, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, const pta_ws_panel &p, double *W,
                              int64_t ldw, int64_t sW, hipStream_t s) {
-  int rc = pta_factor_panel(A, p.pend, lda, strideA, B, p.k0, p.nbo, info, flags, algo, s);
-  if (rc != PTA_OK) return rc;
-  if (p.rows <= 0) return PTA_OK;
-  hipLaunchKernelGGL(k_inv_blocks, dim3(p.nb, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.nbo, p.f128, W, ldw, sW);
-  PTA_LAUNCH_CHECK();
+  int rc;
+  if (p.rows <= 0)  // the last panel: nothing below it needs the inverses
+    return pta_factor_panel(A, p.pend, lda, strideA, B, p.k0, p.nbo, info, flags, algo, s);
+  if (flags & PTA_POTRF_DIAG64) {  // A/B: the 64-column recursion of pta_factor_panel on the diagonal block + one inversion pass
+    if ((rc = pta_factor_panel(A, p.pend, lda, strideA, B, p.k0, p.nbo, info, flags, algo, s)) != PTA_OK) return rc;
+    hipLaunchKernelGGL(k_inv_blocks, dim3(p.nb, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.nbo, p.f128, W, ldw, sW);
+    PTA_LAUNCH_CHECK();
+  } else if ((rc = pta_factor_diag_ws(A, p.pend, lda, strideA, B, p.k0, p.nbo, info, algo, p, W, ldw, sW, s)) != PTA_OK) {
+    return rc;
+  }
   if (p.nb > 1) {
     int groups = 0;
     for (int j = 1; j < p.nb; ++j) groups += ((p.f128 + 128 * (j - 1) + 63) / 64 + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
@@ -646,17 +865,8 @@ static int pta_ws_solve_phase(double *A, int64_t lda, int64_t strideA, int B, in
   double *Bp = A + (int64_t)p.pend * lda + p.k0;
   for (int j = 0; j < p.nb; ++j) {
     const int oj = j == 0 ? 0 : p.f128 + 128 * (j - 1), wj = j == 0 ? p.f128 : 128;
-    const double *Sj = W + (int64_t)j * 128 * ldw;
-    // in place: a launch must cover ONE column tile (a second tile would read columns the first one is overwriting), so a block the
-    // launcher would split (few rows or a narrow block: 64-wide tiles) goes chunk by chunk, right to left (chunk [c0, c1) needs the
-    // block's columns [0, c1) only: W_jj is lower triangular)
-    const int tile = pta_dgemm_tile_n(p.rows, wj, oj + wj, algo);
-    for (int c1 = wj; c1 > 0; c1 -= tile) {
-      const int c0 = c1 > tile ? c1 - tile : 0;
-      int rc = pta_dgemm_launch(1, p.rows, c1 - c0, oj + c1, 1.0, Bp, lda, 1, Sj + (int64_t)c0 * ldw, ldw, 0.0, Bp + oj + c0, lda, 0, B, strideA, sW,
-                                strideA, algo, s);
-      if (rc != PTA_OK) return rc;
-    }
+    int rc = pta_ws_apply_block(Bp + oj, lda, strideA, B, p.rows, wj, oj, W + (int64_t)j * 128 * ldw, ldw, sW, algo, s);
+    if (rc != PTA_OK) return rc;
   }
   return PTA_OK;
 }
@@ -751,8 +961,8 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
-  // default: two chains; ONE with PTA_POTRF_DIAG_AHEAD (what a second chain hides, the look-ahead hides already: 53.6 against 54.1 ms)
-  if (nchain == 0) nchain = (flags & PTA_POTRF_DIAG_AHEAD) ? 1 : 2;
+  // default: two chains (with PTA_POTRF_DIAG_AHEAD and the 128-column base case: 53.2 ms against 54.1 with one chain, 58.3 with three)
+  if (nchain == 0) nchain = 2;
   if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
   if (nchain > B) nchain = B;
   if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;

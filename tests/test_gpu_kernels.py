@@ -203,7 +203,7 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
 
 
 @pytest.mark.parametrize("n,batch,flags", [(1025, 2, 0), (1338, 3, 0), (2500, 2, 0), (2501, 1, 0), (700, 3, "NB1"), (1338, 3, "NB1"), (2500, 2, "NB1C3"),
-                                           (3000, 5, "C4"), (3000, 2, "LA"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1")])
+                                           (3000, 5, "C4"), (3000, 2, "LA"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1"), (2500, 2, "D64"), (2501, 2, "NB1D64LA"), (1200, 3, "LA"), (1290, 2, 0)])
 def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
     over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
@@ -212,7 +212,9 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     fl = {0: 0, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3), "C4": lib.POTRF_CHAINS(4),
           # look-ahead of the next panel's diagonal phase on a side stream (used while >= 1536 rows remain below it)
           "LA": lib.POTRF_DIAG_AHEAD, "NB1LA": lib.POTRF_NB(1) | lib.POTRF_DIAG_AHEAD, "NB1C3LA": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3) | lib.POTRF_DIAG_AHEAD,
-          "NB2LA1": lib.POTRF_NB(2) | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(2)}[flags]
+          "NB2LA1": lib.POTRF_NB(2) | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(1),
+          # A/B path: 64-column recursion on the diagonal block + inversion pass
+          "D64": lib.POTRF_DIAG64, "NB1D64LA": lib.POTRF_NB(1) | lib.POTRF_DIAG64 | lib.POTRF_DIAG_AHEAD}[flags]
     rng = np.random.default_rng(n + batch)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
