@@ -73,7 +73,7 @@ class TimeDomainMixin:
         info = dv.zeros((P,), dtype=torch.int32)
         # workspace scheme of the factorisation (include/pta_replicator_amd.h: pta_potrf_batched_ws): strips [-W_jj L11[j, <j] | W_jj] of
         # the panels' diagonal blocks, 10.6 MB per matrix at the default panel width, released right after the factorisation - and
-        # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.6 ms against 56.5 ms
+        # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.2 ms against 56.5 ms
         # without; td_potrf_workspace = False keeps the workspace-free two-chain schedule.
         use_ws = bool(getattr(self, "td_potrf_workspace", True))
         flags = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
