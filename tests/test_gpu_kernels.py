@@ -60,6 +60,27 @@ def test_rng_fill_matches_numpy_twin(gpu, interleave):
         assert np.max(np.abs(got0[r] - e0)) < 1e-13 and np.max(np.abs(got1[r] - e1)) < 1e-13
 
 
+def test_rng_fill_blocks_equals_the_per_block_fill(gpu):
+    """pta_rng_fill_normal_blocks: every block of a TD plan in one launch - bit-identical to pta_rng_fill_normal per block (stream
+    (kind, b)), odd orders (the pair is written whole), nothing written outside a block's columns."""
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    seed, r0, R, kind = 0x1234ABCD, (1 << 32) + 7, 5, 5
+    ns = [7, 300, 1, 1025, 64]
+    zoff = np.concatenate([[0], np.cumsum([(n + 1) // 2 * 2 + 4 for n in ns])]).astype(np.int64)   # 4 spare columns behind every block
+    ld = int(zoff[-1]) + 16
+    z = dv.empty((R, ld)); z.fill_(-7.0)
+    d_n, d_off = dv.i32(ns), dv.i32(zoff[:-1])
+    lib.call("pta_rng_fill_normal_blocks", seed, r0, R, kind, len(ns), dv.ptr(d_n), dv.ptr(d_off), max(ns), dv.ptr(z), ld, 0, gpu["s"])
+    got = z.cpu().numpy()
+    want = np.full((R, ld), -7.0)
+    for b, n in enumerate(ns):
+        npair = (n + 1) // 2
+        zb = dv.empty((R, 2 * npair))
+        lib.call("pta_rng_fill_normal", seed, r0, R, philox_ref.stream_id(kind, b), npair, 1, dv.ptr(zb), None, 2 * npair, 0, gpu["s"])
+        want[:, zoff[b]:zoff[b] + 2 * npair] = zb.cpu().numpy()
+    assert np.array_equal(got, want)
+
+
 def test_device_deviates_within_a_few_ulp_of_an_80_bit_box_muller(gpu):
     """the table-driven fp64 transform on the device (tables staged in LDS): every deviate within 6 ulp of a long double
     evaluation of the same uniforms, 99.9 % within 3.5 (scripts/gpu_rng_accuracy.py prints the measured figures)."""
