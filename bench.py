@@ -278,15 +278,17 @@ def td_mode_numbers(eng, R):
         # the schedule prepare_td() uses (workspace scheme, next panel's diagonal phase run ahead) and the workspace-free two-chain one
         need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, _lib.POTRF_DIAG_AHEAD))
         work = dv.empty((need,))
-        ts, ts_free = [], []
+        ts, ts_free, bad = [], [], 0
         for _ in range(2):
+            wall(assemble)
+            ts_free.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
+            bad += int(info.abs().sum().item())
+        for _ in range(4):
             ta = wall(assemble)
             ts.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD,
                                              dv.ptr(work), need, s)))
-            bad = int(info.abs().sum().item())
-            wall(assemble)
-            ts_free.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
-            info.add_(bad)
+            bad += int(info.abs().sum().item())
+        info.add_(bad)
         del work
         tp = min(ts)
         res.update({"potrf_workspace_GB": 8.0 * need / 1e9, "potrf_without_workspace_ms": min(ts_free) * 1e3})

@@ -51,7 +51,7 @@ if "potrf" in what:
     work.fill_(float("nan"))
     for name, flags, ws in (("reg_2chains", RS, 0), ("glds_2chains", 0, 0), ("ws_1chain", _lib.POTRF_NO_LOOKAHEAD, 1), ("ws_2chains", 0, 1),
                             ("ws_la_1chain", _lib.POTRF_DIAG_AHEAD | _lib.POTRF_CHAINS(1), 1), ("ws_la_2chains_diag64", _lib.POTRF_DIAG_AHEAD | _lib.POTRF_DIAG64, 1), ("ws_1chain_diag64", _lib.POTRF_NO_LOOKAHEAD | _lib.POTRF_DIAG64, 1),  ("ws_la_2chains", _lib.POTRF_DIAG_AHEAD, 1), ("ws_la_3chains", _lib.POTRF_DIAG_AHEAD | _lib.POTRF_CHAINS(3), 1), ("ws_3chains", _lib.POTRF_CHAINS(3), 1), ("ws_4chains", _lib.POTRF_CHAINS(4), 1),
-                            ("ws_2chains_nb512", _lib.POTRF_NB(2), 2), ("ws_2chains_nb1536", _lib.POTRF_NB(6), 2), ("ws_2chains_nb2048", _lib.POTRF_NB(8), 2),
+                            ("ws_la_2chains_nb512", _lib.POTRF_NB(2) | _lib.POTRF_DIAG_AHEAD, 2), ("ws_la_2chains_nb768", _lib.POTRF_NB(3) | _lib.POTRF_DIAG_AHEAD, 2), ("ws_la_2chains_nb1280", _lib.POTRF_NB(5) | _lib.POTRF_DIAG_AHEAD, 2), ("ws_la_2chains_again", _lib.POTRF_DIAG_AHEAD, 2), ("ws_2chains_nb512", _lib.POTRF_NB(2), 2), ("ws_2chains_nb1536", _lib.POTRF_NB(6), 2), ("ws_2chains_nb2048", _lib.POTRF_NB(8), 2),
                             ("glds_2chains_nb2048", _lib.POTRF_NB(8), 0), ("glds_2chains_nb1536", _lib.POTRF_NB(6), 0)):
         if ws == 2:
             need2 = int(_lib.lib.pta_potrf_workspace_doubles(n, P, flags))
