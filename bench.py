@@ -310,11 +310,17 @@ def td_mode_numbers(eng, R):
                 "td_draws": "memory (deviates written once per batch, read by the product)",
                 "draws_in_registers": {"generate_td_ms": t_reg * 1e3, "realisations_per_s": R / t_reg, "trmm_useful_TFLOPs": flop * R / t_reg / 1e12},
                 "gw_grid_factor_jitter": eng.gw_td_jitter if eng.plan.gw_npts else None})
-    for key, name in (("k_dgemm_glds128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng", "trmm_mfma_busy_pct"),
+    # MFMA-busy % from the committed PMC pass: the tile product over its dispatches of >= 1 ms (the trailing updates; the mean over all
+    # of its launches, small ones included, is carried as ..._all_dispatches), the L.z product for the default (memory) form
+    for key, name in (("k_dgemm_glds128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng<false, true>", "trmm_mfma_busy_pct"),
                       ("k_td_cov128", "cov_assemble_mfma_busy_pct")):
         e, why = pmc_entry(key, TD_SRC, n_psr=eng.P)
-        res[name] = e["mfma_busy_pct"] if e else None
+        big = (e or {}).get("dispatches_over_1ms")
+        res[name] = (big or e)["mfma_busy_pct"] if e else None
         if e:
+            if big:
+                res[name + "_all_dispatches"] = e["mfma_busy_pct"]
+                res[name.replace("mfma_busy_pct", "engine_clock_GHz")] = big["engine_clock_GHz"]
             res[name + "_source"] = e.get("source")
             if key == "k_td_cov128" and e.get("hbm_write_GBps"):   # counter bytes (WRITE_SIZE) over the rocprofv3 launch time
                 res["cov_assemble_GBps_from_WRITE_SIZE"] = e["hbm_write_GBps"]

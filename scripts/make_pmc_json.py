@@ -68,7 +68,33 @@ if nf and nw:
     res[k] = e
 # ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches; HBM bytes from
 # the FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch; this round those passes run WITH TD mode)
-for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_cov128", "k_trsm_mfma", "k_potf2", "k_mb_mfma(", "k_mb_mfma_tile("):
+def large_dispatches(match, min_ms=1.0):
+    """MFMA-busy % and engine clock over the dispatches of `match` that last at least min_ms, durations from the SAME pass's kernel
+    trace (the time-weighted mean over ALL dispatches of a kernel is dominated by its many small launches)."""
+    dur = {}
+    for p in glob.glob(os.path.join(out_dir, "pmc_mfma", "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            if match in r["Kernel_Name"]:
+                dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    gui, busy, tot, n = 0.0, 0.0, 0.0, set()
+    for p in glob.glob(os.path.join(out_dir, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(p)):
+            d = dur.get(r["Dispatch_Id"])
+            if match in r["Kernel_Name"] and d is not None and d >= min_ms:
+                if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                    gui += float(r["Counter_Value"])
+                    if r["Dispatch_Id"] not in n:
+                        n.add(r["Dispatch_Id"])
+                        tot += d
+                elif r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                    busy += float(r["Counter_Value"])
+    if not n or not gui:
+        return None
+    return {"dispatches": len(n), "min_ms": min_ms, "mfma_busy_pct": 100.0 * busy / (gui * SIMD_PER_XCD), "engine_clock_GHz": gui / 8 / (tot * 1e6)}
+
+
+for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_td_trmm_rng<false, false>", "k_td_cov128", "k_diag128", "k_trsm_mfma",
+          "k_potf2", "k_mb_mfma(", "k_mb_mfma_tile("):
     m, nm = sums("pmc_mfma", k)
     ms, nt = avg_ms(k)
     if nm and m.get("GRBM_GUI_ACTIVE"):
@@ -85,6 +111,9 @@ for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_cov128", "k_trsm_mfma", "k_p
             if ms:
                 e["hbm_write_GBps"] = w.get("WRITE_SIZE", 0.0) * 1024.0 / (ms * 1e-3) / 1e9
                 e["hbm_fetch_GBps_uncorrected"] = f.get("FETCH_SIZE", 0.0) * 1024.0 / (ms * 1e-3) / 1e9
+        big = large_dispatches(k)
+        if big:
+            e["dispatches_over_1ms"] = big
         res[k] = e
 json.dump(res, open(os.path.join(out_dir, "r03_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
