@@ -175,8 +175,8 @@ int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, 
 /* The same factorisation with a caller-owned workspace (device memory, `work_doubles` doubles, at least
  * pta_potrf_workspace_doubles(n, B, flags) - B * 1152^2 doubles = 10.6 MB per matrix at the default panel width; 0 = the workspace
  * scheme does not apply: n <= panel width, or the VALU / SUBSTITUTION paths).  With it a panel is factored on its nbo x nbo DIAGONAL
- * block only, the 128 x 128 diagonal blocks of L11 are inverted (W_jj) and the strips S_j = [-W_jj L11[j, <j] | W_jj] go to the
- * workspace, and the rows below are solved by blocked substitution - ONE tile product X_j = [X_{<j} | B_j] S_j^T per 128 columns,
+ * block only - a recursion whose base case is a whole 128-column group, factored AND inverted (W_jj) by one workgroup per matrix -,
+ * the strips S_j = [-W_jj L11[j, <j] | W_jj] go to the workspace, and the rows below are solved by blocked substitution - ONE tile product X_j = [X_{<j} | B_j] S_j^T per 128 columns,
  * K = 128 (j + 1), in place - instead of by the recursion over the panel's full height: no 64-column solves or K = 64 updates over
  * all rows, a quarter of the launches, and what is left of the latency-bound kernels works on the diagonal block's few rows.
  * PTA_POTRF_DIAG_AHEAD additionally runs the next panel's diagonal phase on an internal side stream beside the trailing update.
