@@ -84,6 +84,8 @@ extern "C" int pta_orf_combine(const double *basis, const double *clm, int nbasi
 // The 64-step sweep of k_potf2 on a tile held in the registers of 256 threads (v[a][b] = element (ti + 16 a, tc + 16 b); lower
 // triangle + diagonal loaded, zeros above); colbuf = the workgroup's double-buffered pivot column.  Shared with k_diag128.
 __device__ __forceinline__ void pta_potf2_sweep(double (&v)[4][4], double (*colbuf)[CH_NB], int nb, int ti, int tc, int32_t *info_b, int col0) {
+  int bad = 0;  // first pivot that is not positive (LAPACK's info), the same value in every thread; stored once, after the sweep
+  const bool diag_ge = ti >= tc;  // p >= q inside a diagonal 16 x 16 sub-block (a == b)
 #pragma unroll
   for (int jq = 0; jq < 4; ++jq) {
     for (int jr = 0; jr < 16; ++jr) {
@@ -104,27 +106,28 @@ __device__ __forceinline__ void pta_potf2_sweep(double (&v)[4][4], double (*colb
       for (int a = 0; a < 4; ++a) cp[a] = cb[ti + 16 * a] * r;
 #pragma unroll
       for (int b = 0; b < 4; ++b) cq[b] = cb[tc + 16 * b] * r;
+      bad = (!(d > 0.0) && bad == 0) ? col0 + j + 1 : bad;
+      // the step as selects (no branch, no store): with a, b, jq compile-time most of the conditions fold away - what is left per step
+      // are four comparisons of (ti, tc) with jr and the selects of the sub-blocks in row / column jq
+      const bool c_gt = tc > jr, c_eq = tc == jr, r_lt = ti < jr, r_eq = ti == jr;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int p = ti + 16 * a, q = tc + 16 * b;
-          if (q > j) {
-            if (p >= q || p < j)
-              v[a][b] = fma(-cp[a], cq[b], v[a][b]);
-            else if (p == j)
-              v[a][b] = -cq[b] * r;
-          } else if (q == j) {
-            if (p != j)
-              v[a][b] = cp[a];        // column j scaled
-            else {
-              if (!(d > 0.0) && *info_b == 0) *info_b = col0 + j + 1;  // LAPACK: leading minor j+1 not PD
-              v[a][b] = d * r;        // L[j][j] = sqrt(d)
-            }
-          }
+          if (b < jq) continue;                                           // q < j: finished columns
+          const bool qg = b > jq || c_gt;                                 // q > j
+          const bool qe = b == jq && c_eq;                                // q == j
+          const bool pl = a < jq || (a == jq && r_lt);                    // p < j
+          const bool pe = a == jq && r_eq;                                // p == j
+          const bool pgq = a > b || (a == b && diag_ge);                  // p >= q
+          double nv = (qg && (pgq || pl)) ? fma(-cp[a], cq[b], v[a][b]) : v[a][b];   // Schur complement of L / X[q][p]
+          nv = (qg && pe) ? -cq[b] * r : nv;                              // X[q][j] = -L[q][j] / L[j][j]
+          nv = qe ? (pe ? d * r : cp[a]) : nv;                            // column j scaled; L[j][j] = sqrt(d)
+          v[a][b] = nv;
         }
     }
   }
+  if (bad && ti == 0 && tc == 0 && *info_b == 0) *info_b = bad;
 }
 
 __global__ __launch_bounds__(256) void k_potf2(double *__restrict__ A, int64_t n, int64_t sA, int k0, int nb, int32_t *__restrict__ info) {
