@@ -96,13 +96,16 @@ def build_engine(P, N, seed):
 
 
 def src_sha(*files):
-    """sha256 over the kernel sources a profile was taken with: a PMC figure in profiles/*.json is only quoted while the
-    sources that produced it are unchanged."""
+    """sha256 over the CODE of the kernel sources a profile was taken with (comments and white space removed: a reworded comment does
+    not invalidate a measurement): a PMC figure in profiles/*.json is only quoted while the sources that produced it are unchanged."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in files:
-        with open(os.path.join(ROOT, "pta_replicator_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(ROOT, "pta_replicator_amd", "csrc", f), "r") as fh:
+            code = re.sub(r"/\*.*?\*/", " ", fh.read(), flags=re.S)
+            code = re.sub(r"//[^\n]*", " ", code)
+            h.update(" ".join(code.split()).encode())
     return h.hexdigest()[:16]
 
 
