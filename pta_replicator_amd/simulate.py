@@ -100,16 +100,24 @@ class ArrayTOAs:
     def ntoas(self):
         return len(self.mjd_ld)
 
+    def _mjd_f64(self):
+        """the MJDs rounded to float64, converted once per TOA state (adjust_TOAs REPLACES mjd_ld, so the array's identity is the
+        state): get_mjds / first_MJD / last_MJD of 68 pulsars cost 2.6 ms per add_gwb as longdouble reductions and conversions."""
+        c = getattr(self, "_f64", None)
+        if c is None or c[0] is not self.mjd_ld:
+            c = self._f64 = (self.mjd_ld, self.mjd_ld.astype(np.float64))
+        return c[1]
+
     def get_mjds(self):
-        return self.mjd_ld.astype(np.float64) * u.day
+        return self._mjd_f64().copy() * u.day     # a copy: the caller owns what it gets
 
     @property
     def first_MJD(self):
-        return _Scalar(float(self.mjd_ld.min()))
+        return _Scalar(float(self._mjd_f64().min()))   # rounding is monotone: the rounded minimum IS the minimum of the rounded values
 
     @property
     def last_MJD(self):
-        return _Scalar(float(self.mjd_ld.max()))
+        return _Scalar(float(self._mjd_f64().max()))
 
     def get_errors(self):
         return self.errors_us.copy() * u.us
