@@ -405,3 +405,22 @@ def test_native_legacy_normal_stream_equals_numpy_value_for_value():
         outs.append(flat)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.array_equal(outs[0][:777], np.random.RandomState(100).randn(777))
+
+
+def test_array_toas_float64_view_follows_the_toa_state():
+    """ArrayTOAs caches the float64 rounding of its longdouble MJDs per TOA state: every accessor sees adjust_TOAs / reset_ideal,
+    first_MJD / last_MJD equal the rounded longdouble extremes, and what get_mjds hands out is the caller's to modify."""
+    from pta_replicator_amd.simulate import ArrayTOAs
+    from pta_replicator_amd._compat import TimeDelta, u
+    rng = np.random.default_rng(4)
+    mjd = rng.uniform(53000, 58000, 257)
+    t = ArrayTOAs(mjd, 0.5)
+    m0 = t.get_mjds().value
+    assert np.array_equal(m0, t.mjd_ld.astype(np.float64)) and t.first_MJD.value == float(t.mjd_ld.min()) and t.last_MJD.value == float(t.mjd_ld.max())
+    m0 *= 0.0                                             # the caller's copy
+    assert np.array_equal(t.get_mjds().value, t.mjd_ld.astype(np.float64))
+    t.adjust_TOAs(TimeDelta((rng.uniform(-40, 40, 257)) * u.day))
+    assert np.array_equal(t.get_mjds().value, t.mjd_ld.astype(np.float64))
+    assert t.first_MJD.value == float(t.mjd_ld.min()) and t.last_MJD.value == float(t.mjd_ld.max())
+    t.reset_ideal()
+    assert np.array_equal(t.get_mjds().value, mjd) and t.first_MJD.value == mjd.min()
