@@ -333,6 +333,172 @@ def td_mode_numbers(eng, R):
     return res
 
 
+def ragged_counts(P=42, lo=500, hi=35000):
+    """an ng15-like spread of TOA counts: P quantiles of the log-uniform distribution on [lo, hi] (P = 42: sum N_a = 340 915, the
+    headline array's total; 48 GB of factors, 46.9 TFLOP of factorisation), shuffled so that the array order is not the size order."""
+    n = np.round(lo * (hi / lo) ** ((np.arange(P) + 0.5) / P)).astype(int)
+    return [int(x) for x in np.random.default_rng(P).permutation(n)]
+
+
+def ragged_array(counts, seed=42):
+    """pulsars with the given TOA counts over the headline span, ng15 noise values cycled (as headline_array)."""
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    nd = ng15_noise()
+    names = list(nd["pulsars"])
+    rng = np.random.default_rng(seed)
+    P = len(counts)
+    raj = rng.uniform(0, 24, P)
+    decj = np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
+    psrs = []
+    noise = dict(flags=[], efac=[], log10_equad=[], log10_ecorr=[], rn_log10_A=[], rn_gamma=[], gw_log10_A=float(nd["gw_log10_A"]))
+    for a, N in enumerate(counts):
+        name = names[a % len(names)]
+        rec = nd["pulsars"][name]
+        be = rec["backends"]
+        mjd = np.sort(rng.uniform(53000, 58478, N))
+        which = rng.integers(0, len(be), N)
+        psr = SimulatedPulsar(toas=ArrayTOAs(mjd, 0.5, flags=[{"f": be[k]} for k in which]), name=f"{name}_{a}", loc={"RAJ": float(raj[a]), "DECJ": float(decj[a])})
+        make_ideal(psr)
+        psrs.append(psr)
+        noise["flags"].append(list(be))
+        noise["efac"].append(np.array([1.0 if v is None else v for v in rec["efac"]]))
+        noise["log10_equad"].append(np.array(rec["log10_t2equad"]))
+        noise["log10_ecorr"].append(np.array(rec["log10_ecorr"]))
+        noise["rn_log10_A"].append(rec["red_noise_log10_A"])
+        noise["rn_gamma"].append(rec["red_noise_gamma"])
+    return psrs, noise
+
+
+def _wall(fn, reps=1):
+    import torch
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def td_ragged_numbers(P=42, R=256, compare_per_matrix=True):
+    """TD mode on an ng15-like RAGGED array (VERDICT r3 #1b): TOA counts log-uniform 500 ... 35 000, sum = 340 k - the normal shape of real
+    data (the reference loops over pulsars: red_noise.py:286-298).  `potrf` = ALL pulsars as one end-aligned schedule (pta_potrf_ragged);
+    `per_matrix` = the batch-by-equal-order scheme of rounds 1-3 on the same array (P batches of one)."""
+    import torch
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd import device as dv
+    counts = ragged_counts(P)
+    psrs, noise = ragged_array(counts)
+    eng = configure_engine(ReplicaEngine(psrs, seed=7), noise)
+    eng.prepare()
+    eng.prepare_td()
+    flop = sum(float(n) ** 3 for n in counts) / 3.0
+    res = {"n_psr": P, "n_toa_min": min(counts), "n_toa_max": max(counts), "n_toa_total": int(sum(counts)), "factor_buffer_GB": eng.d_Ltd.numel() * 8 / 1e9,
+           "potrf_TFLOP": flop / 1e12, "schedule": eng.td_potrf_mode_used}
+    ta = min(_wall(eng.td_assemble) for _ in range(2))
+    res["cov_assemble_ms"] = ta * 1e3
+
+    def timed_factor(mode):
+        ts = []
+        for _ in range(2):
+            eng.td_assemble()
+            ts.append(_wall(lambda: eng.td_factorise(mode=mode)))
+        return min(ts)
+    t_r = timed_factor("ragged")
+    res.update({"potrf_ms": t_r * 1e3, "potrf_TFLOPs": flop / t_r / 1e12, "potrf_frac_of_fp64_mfma_peak": flop / t_r / 1e12 / FP64_MFMA_PEAK_TFLOPS})
+    if compare_per_matrix:
+        t_u = timed_factor("uniform")
+        res["per_matrix_schedule"] = {"potrf_ms": t_u * 1e3, "potrf_TFLOPs": flop / t_u / 1e12, "note": "batches of one (rounds 1-3: runs of equal TOA count share a launch sequence)"}
+        eng.td_assemble()
+        eng.td_factorise(mode="ragged")
+    out = dv.empty((R, eng.n_toa))
+    eng.generate_td(R, out=out)
+    t = _wall(lambda: eng.generate_td(R, out=out), 2)
+    fl = float(sum(float(n) ** 2 for n in counts))
+    res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t, "trmm_useful_TFLOPs": fl * R / t / 1e12,
+                "trmm_frac_of_fp64_mfma_peak": fl * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS, "finite": bool(torch.isfinite(out).all())})
+    return res
+
+
+def grid_cell(P, N, td=True, seed=20260921, td_gb_limit=200.0):
+    """one (N_psr, N_toa) cell of the north_star's grid: the headline workload's recipe (ng15 noise values cycled, HD GWB + RN + per-backend
+    EFAC / EQUAD / ECORR) at P pulsars x N TOAs - throughput mode (realisations/s, per-kernel ms, fractions of the 8 TB/s and 78.6 TFLOP/s
+    roofs) and TD mode (assembly, batched Cholesky, L.z) where the factors fit."""
+    import ctypes
+    import torch
+    from pta_replicator_amd import _lib, device as dv
+    t0 = time.perf_counter()
+    eng, psrs, noise = build_engine(P, N, seed)
+    torch.cuda.synchronize()
+    cell = {"n_psr": P, "n_toa": N, "prepare_s": time.perf_counter() - t0}
+    ntot = eng.n_toa
+    R = int(max(16, min(1024, (6 << 30) // (8 * ntot)) // 16 * 16))
+    out = dv.empty((R, ntot))
+    eng.generate(R, out=out)
+    one = _wall(lambda: eng.generate(R, out=out))
+    K = int(max(2, min(50, 0.4 / max(one, 1e-4))))
+    step = _wall(lambda: eng.generate(R, out=out), K)
+    npts, Nf = eng.plan.gw_npts, eng.grid["Nf"]
+    s = dv.stream_ptr()
+    ws = eng.workspace(R)
+    kern = {}
+
+    def timed(name, fn, reps=3):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        fn(); torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record(); torch.cuda.synchronize()
+        kern[name] = ev[0].elapsed_time(ev[1]) / reps
+    gwb_kernel = "pta_gwb_czt" if eng.use_czt else "pta_gwb_idft_rng"
+    if eng.use_czt:
+        timed("pta_gwb_czt", lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt], dv.ptr(ws["G0"]), npts, 0, 0, s))
+    else:
+        timed("pta_gwb_idft_rng", lambda: _lib.call("pta_gwb_idft_rng", eng.seed, 0, R, P, Nf, dv.ptr(eng.d_Tsym), dv.ptr(eng.d_rot), npts, dv.ptr(ws["G0"]), npts, eng.idft_variant, 0, s))
+    timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), 0, s))
+    timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
+    n_fft = 2 * Nf - 2
+    n_epochs = int(sum(len(v) for v in eng.ecorrvec))
+    flops_alg = 4.0 * P * P * Nf + 5.0 * n_fft * np.log2(n_fft) * P + 2.0 * eng.K * ntot + 10.0 * ntot
+    dom = max(kern, key=kern.get)
+    cell["throughput"] = {"realisations_per_step": R, "ms_per_step": step * 1e3, "realisations_per_s": R / step, "toa_per_s": R * ntot / step,
+                          "kernels_ms": {k: round(v, 4) for k, v in kern.items()}, "dominant_kernel": dom,
+                          "synth_alg_bytes_frac_of_hbm": 8.0 * ntot * R / (kern["pta_engine_synth"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "step_alg_bytes_frac_of_hbm": 8.0 * ntot * R / step / 1e9 / HBM_PEAK_GBS,
+                          "step_frac_of_fp64_peak": flops_alg * R / step / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                          "tiles": int(eng.plan.n_tiles), "tile_fill": ntot / (eng.plan.n_tiles * 256.0), "Nf": int(Nf), "npts": int(npts)}
+    del out
+    if td:
+        gb = 8.0 * P * float(N + (N & 1)) * ((N + (N & 1) + 15) // 16 * 16) / 1e9
+        if gb > td_gb_limit:
+            cell["td"] = {"skipped": f"{gb:.0f} GB of factors do not fit beside the workspace"}
+        else:
+            try:
+                eng.prepare_td()
+                flop = P * float(N) ** 3 / 3.0
+                ta = min(_wall(eng.td_assemble) for _ in range(2))
+                tf = []
+                for _ in range(2):
+                    eng.td_assemble()
+                    tf.append(_wall(eng.td_factorise))
+                tf = min(tf)
+                Rt = int(max(32, min(1024, (3 << 30) // (8 * ntot)) // 32 * 32))
+                o2 = dv.empty((Rt, ntot))
+                eng.generate_td(Rt, out=o2)
+                tg = _wall(lambda: eng.generate_td(Rt, out=o2), 2)
+                cell["td"] = {"factor_GB": gb, "schedule": eng.td_potrf_mode_used, "cov_assemble_ms": ta * 1e3, "cov_assemble_TBps_written": 8.0 * P * N * (N + 64) / 2 / ta / 1e12,
+                              "potrf_ms": tf * 1e3, "potrf_TFLOPs": flop / tf / 1e12, "potrf_frac": flop / tf / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                              "generate_td_realisations": Rt, "generate_td_ms": tg * 1e3, "realisations_per_s": Rt / tg,
+                              "trmm_useful_TFLOPs": P * float(N) ** 2 * Rt / tg / 1e12, "trmm_frac": P * float(N) ** 2 * Rt / tg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                              "finite": bool(torch.isfinite(o2).all())}
+                del o2
+            except Exception as e:  # pragma: no cover
+                cell["td"] = {"error": str(e)[:300]}
+    eng.d_Ltd = None
+    del eng
+    torch.cuda.empty_cache()
+    return cell
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

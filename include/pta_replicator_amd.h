@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 5
+#define PTA_ABI_VERSION 6
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -185,6 +185,27 @@ int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, 
 int64_t pta_potrf_workspace_doubles(int n, int B, int flags);
 int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
                          int64_t work_doubles, void *stream);
+
+/* RAGGED batch (ABI 6): B matrices of DIFFERENT orders factored as ONE schedule - the shape of a real pulsar timing array (the
+ * reference's noise_dicts/ng15_dict.json: 68 pulsars, 68 TOA counts; test_partim: 7758 / 23023 / 35037 TOAs), which the reference
+ * handles by looping over pulsars (red_noise.py:286-298) and a batch-by-equal-order scheme would run as B batches of one.
+ * Matrix b: order n[b], row-major lower triangle at A + off[b], leading dimension ld[b]; n, off, ld are HOST arrays, all entries
+ * EVEN (16-byte operand rows: pad an odd order with an identity row / column at its end) and ld[b] >= n[b].
+ * The matrices are end-aligned: embedded in a virtual matrix whose bottom-right corner they share, so that at every time step
+ * (one panel of NB = 1024 columns counted from the END) all matrices that have been reached have the same panel boundaries,
+ * trailing size and tile grids - every kernel of the step is one launch over them; a matrix enters at the step that contains its
+ * first column, with the panel cut at its front (masked inside the kernels).  The diagonal phases (latency chains) are paid once
+ * per time step instead of once per matrix and panel.  Chains / look-ahead / workspace scheme as pta_potrf_batched_ws.
+ *   1. pta_potrf_ragged_plan(n, off, ld, B, flags, plan_host, &work_doubles) fills plan_host[pta_potrf_ragged_plan_words(B)]
+ *      (int64 words; flags: PTA_POTRF_CHAINS / PTA_POTRF_NB / PTA_POTRF_NO_LOOKAHEAD) and returns the workspace size;
+ *   2. the caller copies the plan to device memory (plan_dev) - it is reusable for any number of factorisations of this layout;
+ *   3. pta_potrf_ragged(A, plan_host, plan_dev, info, work, work_doubles, stream): asynchronous; info[b] (device, caller's order)
+ *      = 0 or the 1-based index of the first non-positive pivot of matrix b.  The upper triangles are left holding scratch.   */
+int64_t pta_potrf_ragged_plan_words(int B);
+int pta_potrf_ragged_plan(const int32_t *n, const int64_t *off, const int64_t *ld, int B, int flags, int64_t *plan_host,
+                          int64_t *work_doubles);
+int pta_potrf_ragged(double *A, const int64_t *plan_host, const int64_t *plan_dev, int32_t *info, double *work,
+                     int64_t work_doubles, void *stream);
 
 
 /* ---------------------------------------------------------------- GWB -------------- */

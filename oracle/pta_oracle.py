@@ -597,6 +597,24 @@ def td_covariance(toas_s, log10_amplitude, spectral_index, components, sigma2_wn
     return Cm
 
 
+def td_covariance_rows(toas_s, log10_amplitude, spectral_index, components, sigma2_wn, epoch_of, ecorr_epoch, rows):
+    """rows `rows` of td_covariance() without forming the N x N matrix (N = 35 037 for BASELINE.json config 2's largest pulsar:
+    9.8 GB): [len(rows), N].  log10_amplitude None = no red noise."""
+    toas_s = np.asarray(toas_s, dtype=np.float64)
+    rows = np.asarray(rows)
+    out = np.zeros((len(rows), len(toas_s)))
+    if log10_amplitude is not None:
+        Tspan = toas_s.max() - toas_s.min()
+        F, freqs = fourier_design_matrix(toas_s, nmodes=components, Tspan=Tspan)
+        phi = red_noise_prior(freqs, log10_amplitude, spectral_index, Tspan)
+        out += (F[rows] * phi[None, :]) @ F.T
+    out[np.arange(len(rows)), rows] += np.asarray(sigma2_wn)[rows]
+    if epoch_of is not None:
+        e2 = ecorr_epoch[epoch_of] ** 2
+        out += (epoch_of[rows][:, None] == epoch_of[None, :]) * e2[rows][:, None]
+    return out
+
+
 def td_draw(Cm, z):
     """L z with L = cholesky(C) lower; z is [N] or [N, R]."""
     return np.linalg.cholesky(Cm) @ z

@@ -82,6 +82,9 @@ _SIGNATURES = {
     "pta_potrf_batched_ex": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P]),
     "pta_potrf_workspace_doubles": (c_int64, [c_int, c_int, c_int]),
     "pta_potrf_batched_ws": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P, c_int64, _P]),
+    "pta_potrf_ragged_plan_words": (c_int64, [c_int]),
+    "pta_potrf_ragged_plan": (c_int, [_P, _P, _P, c_int, c_int, _P, POINTER(c_int64)]),
+    "pta_potrf_ragged": (c_int, [_P, _P, _P, _P, _P, c_int64, _P]),
     "pta_gwb_twiddle": (c_int, [_P, c_int, c_int, c_int, c_double, _P, c_int64, _P]),
     "pta_gwb_idft": (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
     "pta_gwb_twiddle_sym_size": (c_int64, [c_int, c_int, c_int, POINTER(c_int64)]),
@@ -134,7 +137,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.pta_abi_version() != 5:
+if lib.pta_abi_version() != 6:
     raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
 
 

@@ -42,3 +42,22 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
                      int64_t sA, int64_t sB, int64_t sC, int algo, hipStream_t stream);
 
 int pta_dgemm_tile_n(int M, int N, int K, int algo);
+
+// ---- ragged batches (pta_potrf_ragged): matrices of different orders in END-ALIGNED virtual coordinates -------------------------
+// Every matrix of the batch is embedded in a virtual matrix of order E whose bottom-right corner it shares: virtual index i <-> real
+// index i - front[b], front[b] = E - n[b].  In these coordinates every panel boundary, trailing size and tile grid of the blocked
+// factorisation is THE SAME for all matrices that are active at a step - what differs per matrix is where its storage lies (off,
+// ld) and where it begins (front): rows / columns / K indices below `front` do not exist and are masked.
+//   off[b]   offset (doubles) of VIRTUAL element (0, 0) of matrix b from the batch's base pointer (may be negative; only indices
+//            >= front are ever dereferenced);  ld[b] its leading dimension;  front[b] its first real row / column.
+struct pta_rag {
+  const int64_t *off;
+  const int64_t *ld;
+  const int64_t *front;
+};
+// C[r0 + m, c0 + n] = alpha * sum_k A[r0 + m, k0 + k] * Bop[n, k] + beta * C[...] for every matrix b < batch of a ragged batch (m < M,
+// n < N, k < K in virtual coordinates, masked below front[b]); Bop[n, k] = the matrix's own element [c0 + n, k0 + k] when Bws is NULL,
+// else Bws[b * sB + n * ldb + k] (a uniformly strided workspace operand whose k index follows the same virtual columns).
+// lower_only: only c0 + n <= r0 + m (the caller passes r0 == c0 for square updates).  Needs algo >= 1 kernels; all origins even.
+int pta_dgemm_launch_rag(int M, int N, int K, double alpha, double *Abase, int r0, int c0, int k0, const double *Bws, int64_t ldb, int64_t sB,
+                         double beta, int lower_only, int batch, pta_rag rg, hipStream_t stream);

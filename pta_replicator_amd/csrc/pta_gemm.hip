@@ -22,16 +22,35 @@
 #define GBK 16
 #define GLD 80
 
-template <bool BT>
+// RAG: a ragged batch in end-aligned virtual coordinates (pta_common.h: pta_rag) - A / C (and B unless `bws`) are the batch's base
+// pointer, the operands' origins come from (r0, c0, kv0) and the matrix's own offset / leading dimension, and rows < mbeg, columns
+// < nbeg, k < kbeg (everything below the matrix's `front`) are masked: loads clamped into the valid range, products of masked k slots
+// zeroed, stores predicated.
+template <bool BT, bool RAG = false>
 __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                     int64_t lda, int64_t ska, const double *__restrict__ B, int64_t ldb,
                                                     double beta, double *__restrict__ C, int64_t ldc, int lower_only,
-                                                    int64_t sA, int64_t sB, int64_t sC) {
+                                                    int64_t sA, int64_t sB, int64_t sC, pta_rag rg = pta_rag{nullptr, nullptr, nullptr},
+                                                    int r0 = 0, int c0 = 0, int kv0 = 0, int bws = 0) {
   const int bm = blockIdx.y, bn = blockIdx.x;
   if (lower_only && bn * GBN > bm * GBM + (GBM - 1)) return;  // tile entirely above the diagonal
-  A += (int64_t)blockIdx.z * sA;
-  B += (int64_t)blockIdx.z * sB;
-  C += (int64_t)blockIdx.z * sC;
+  int mbeg = 0, nbeg = 0, kbeg = 0;
+  if (RAG) {
+    const int64_t o = rg.off[blockIdx.z], l = rg.ld[blockIdx.z];
+    const int f = (int)rg.front[blockIdx.z];
+    mbeg = max(0, f - r0), nbeg = max(0, f - c0), kbeg = max(0, f - kv0);
+    if ((bm + 1) * GBM <= mbeg || (bn + 1) * GBN <= nbeg || mbeg >= M || nbeg >= N) return;
+    if (kbeg >= K && beta == 1.0) return;
+    B = bws ? B + (int64_t)blockIdx.z * sB : A + o + (int64_t)c0 * l + kv0;
+    C = const_cast<double *>(A) + o + (int64_t)r0 * l + c0;
+    A = A + o + (int64_t)r0 * l + kv0;
+    lda = l, ldc = l;
+    if (!bws) ldb = l;
+  } else {
+    A += (int64_t)blockIdx.z * sA;
+    B += (int64_t)blockIdx.z * sB;
+    C += (int64_t)blockIdx.z * sC;
+  }
   __shared__ double As[GBK][GLD];
   __shared__ double Bs[GBK][GLD];
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
@@ -54,22 +73,22 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cv[i][j][r] = C[(int64_t)min(rowb + i * 16 + 4 * r, M - 1) * ldc + min(colb + j * 16, N - 1)];
+          cv[i][j][r] = C[(int64_t)min(max(rowb + i * 16 + 4 * r, mbeg), M - 1) * ldc + min(max(colb + j * 16, nbeg), N - 1)];
   }
 
-  for (int k0 = 0; k0 < K; k0 += GBK) {
+  for (int k0 = (kbeg / GBK) * GBK; k0 < K; k0 += GBK) {
     // slab loads: unconditional, from clamped (always valid) addresses, all issued before the first select - predicated, each
     // load sits in its own exec-masked block and is waited for on its own
     double la[4], lb[4];
     {  // A slab: 64 rows x 16 k, 4 consecutive k per thread
-      const int gm = min(m0 + (t >> 2), M - 1), kq = (t & 3) * 4;
+      const int gm = min(max(m0 + (t >> 2), mbeg), M - 1), kq = (t & 3) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) la[j] = A[(int64_t)gm * lda + (int64_t)min(k0 + kq + j, K - 1) * ska];
+      for (int j = 0; j < 4; ++j) la[j] = A[(int64_t)gm * lda + (int64_t)min(max(k0 + kq + j, kbeg), K - 1) * ska];
     }
     if (BT) {  // B given as [N x K]: element (k, n) at B[n*ldb + k]
-      const int gn = min(n0 + (t >> 2), N - 1), kq = (t & 3) * 4;
+      const int gn = min(max(n0 + (t >> 2), nbeg), N - 1), kq = (t & 3) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lb[j] = B[(int64_t)gn * ldb + min(k0 + kq + j, K - 1)];
+      for (int j = 0; j < 4; ++j) lb[j] = B[(int64_t)gn * ldb + min(max(k0 + kq + j, kbeg), K - 1)];
     } else {  // B given as [K x N]: coalesced along n
       const int gk = min(k0 + (t >> 4), K - 1), nq = (t & 15) * 4;
 #pragma unroll
@@ -79,13 +98,13 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
       const int row = t >> 2, kq = (t & 3) * 4;
       const bool rin = m0 + row < M;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) As[kq + j][row] = (rin && k0 + kq + j < K) ? la[j] : 0.0;
+      for (int j = 0; j < 4; ++j) As[kq + j][row] = (rin && k0 + kq + j < K && k0 + kq + j >= kbeg) ? la[j] : 0.0;
     }
     if (BT) {
       const int col = t >> 2, kq = (t & 3) * 4;
       const bool cin = n0 + col < N;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Bs[kq + j][col] = (cin && k0 + kq + j < K) ? lb[j] : 0.0;
+      for (int j = 0; j < 4; ++j) Bs[kq + j][col] = (cin && k0 + kq + j < K && k0 + kq + j >= kbeg) ? lb[j] : 0.0;
     } else {
       const int kr = t >> 4, nq = (t & 15) * 4;
       const bool kin = k0 + kr < K;
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double 
         const int row = rowb + i * 16 + 4 * r, col = colb + j * 16;
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v = fma(beta, cv[i][j][r], v);
-        if (row < M && col < N && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
+        if (row < M && col < N && row >= mbeg && col >= nbeg && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
       }
 }
 
@@ -333,9 +352,15 @@ __device__ __forceinline__ int pta_gl_f(int row) {
   return (e & 1) | (((e >> 2) & 1) * 6);
 }
 
+// RAG (pta_common.h: pta_rag): a ragged batch in end-aligned virtual coordinates - operand origins from (r0, c0, kv0) and the matrix's own
+// offset / leading dimension; rows < mbeg, columns < nbeg and k < kbeg (= below the matrix's `front`) are masked: DMA sources clamped into
+// the valid range, the fragments of masked k slots zeroed in the one slab that straddles kbeg (the K loop starts at that slab), stores
+// predicated; tiles wholly below the front leave at once.  The uniform instantiation carries none of it.
+template <bool RAG>
 __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, double alpha, const double *__restrict__ A, int64_t lda,
                                                           const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C,
-                                                          int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC) {
+                                                          int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC, pta_rag rg, int r0,
+                                                          int c0v, int kv0, int bws) {
   int bm = blockIdx.y, bn = blockIdx.x;
   if (lower_only == 2) {
     const int tix = blockIdx.x;
@@ -346,9 +371,23 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
   } else if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) {
     return;
   }
-  A += (int64_t)blockIdx.z * sA;
-  B += (int64_t)blockIdx.z * sB;
-  C += (int64_t)blockIdx.z * sC;
+  int mbeg = 0, nbeg = 0, kbeg = 0;
+  if (RAG) {
+    const int64_t o = rg.off[blockIdx.z], l = rg.ld[blockIdx.z];
+    const int f = (int)rg.front[blockIdx.z];
+    mbeg = max(0, f - r0), nbeg = max(0, f - c0v), kbeg = max(0, f - kv0);
+    if ((bm + 1) * HBM_T <= mbeg || (bn + 1) * HBM_T <= nbeg || mbeg >= M || nbeg >= N) return;
+    if (kbeg >= K && beta == 1.0) return;
+    B = bws ? B + (int64_t)blockIdx.z * sB : A + o + (int64_t)c0v * l + kv0;
+    C = const_cast<double *>(A) + o + (int64_t)r0 * l + c0v;
+    A = A + o + (int64_t)r0 * l + kv0;
+    lda = l, ldc = l;
+    if (!bws) ldb = l;
+  } else {
+    A += (int64_t)blockIdx.z * sA;
+    B += (int64_t)blockIdx.z * sB;
+    C += (int64_t)blockIdx.z * sC;
+  }
   __shared__ double __attribute__((aligned(256))) slab[2][2][HBM_T * GBK];  // [stage][operand][row * 16 + k], swizzled per row
   const int t = threadIdx.x, l = t & 63, w = t >> 6;
   const int wm = w >> 1, wn = w & 1;
@@ -362,13 +401,13 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
   for (int j = 0; j < 4; ++j) {
     const int row = 32 * w + 8 * j + (l >> 3);
     kc[j] = 2 * ((l & 7) ^ pta_gl_f(row));
-    srcA[j] = A + (int64_t)min(m0 + row, M - 1) * lda;
-    srcB[j] = B + (int64_t)min(n0 + row, N - 1) * ldb;
+    srcA[j] = A + (int64_t)min(RAG ? max(m0 + row, mbeg) : m0 + row, M - 1) * lda;
+    srcB[j] = B + (int64_t)min(RAG ? max(n0 + row, nbeg) : n0 + row, N - 1) * ldb;
   }
   auto stage = [&](int k0, int st) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int k = min(k0 + kc[j], K - 2);
+      const int k = min(RAG ? max(k0 + kc[j], kbeg) : k0 + kc[j], K - 2);
       char *dA = reinterpret_cast<char *>(&slab[st][0][0]) + (32 * w + 8 * j) * GL_ROWB;
       char *dB = reinterpret_cast<char *>(&slab[st][1][0]) + (32 * w + 8 * j) * GL_ROWB;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcA[j] + k),
@@ -389,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
     for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
   // one slab: 16 fragment reads (the eight that feed MFMA steps 0 / 1 first), then 64 MFMAs.  `kv` < 16 only for a K tail, which runs
   // as a peeled last iteration so that the steady-state loop carries no selects and its waits stay progressive.
-  auto slab_product = [&](int cur, int kv, int next_k0) {
+  auto slab_product = [&](int cur, int kv, int next_k0, int kh = 0) {
     const char *pa = reinterpret_cast<const char *>(&slab[cur][0][0]) + offA;
     const char *pb = reinterpret_cast<const char *>(&slab[cur][1][0]) + offB;
     pta_f64x2 a0[4], b0[4], a1[4], b1[4];
@@ -410,6 +449,15 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
         if (4 * fq + 1 >= kv) a0[i].y = 0.0, b0[i].y = 0.0;
         if (4 * fq + 2 >= kv) a1[i].x = 0.0, b1[i].x = 0.0;
         if (4 * fq + 3 >= kv) a1[i].y = 0.0, b1[i].y = 0.0;
+      }
+    }
+    if (RAG && kh > 0) {  // K head of a ragged matrix: slots below its front (clamped duplicates / unwritten workspace)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (4 * fq + 0 < kh) a0[i].x = 0.0, b0[i].x = 0.0;
+        if (4 * fq + 1 < kh) a0[i].y = 0.0, b0[i].y = 0.0;
+        if (4 * fq + 2 < kh) a1[i].x = 0.0, b1[i].x = 0.0;
+        if (4 * fq + 3 < kh) a1[i].y = 0.0, b1[i].y = 0.0;
       }
     }
 #pragma unroll
@@ -438,13 +486,16 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
     __builtin_amdgcn_sched_barrier(0);
   };
   const int nfull = K / GBK, ktail = K - nfull * GBK, nslab = nfull + (ktail ? 1 : 0);
-  stage(0, 0);
-  __syncthreads();  // drains the DMA (vmcnt(0)) before any wave reads the slab
-  for (int sidx = 0; sidx < nfull; ++sidx) {
-    slab_product(sidx & 1, GBK, sidx + 1 < nslab ? (sidx + 1) * GBK : -1);
-    __syncthreads();  // every wave is done reading this slab; the DMA of the next one has landed
+  const int s0 = RAG ? kbeg / GBK : 0;  // first slab with a valid k
+  if (!RAG || s0 < nslab) {
+    stage(s0 * GBK, s0 & 1);
+    __syncthreads();  // drains the DMA (vmcnt(0)) before any wave reads the slab
+    for (int sidx = s0; sidx < nfull; ++sidx) {
+      slab_product(sidx & 1, GBK, sidx + 1 < nslab ? (sidx + 1) * GBK : -1, (RAG && sidx == s0) ? kbeg - s0 * GBK : 0);
+      __syncthreads();  // every wave is done reading this slab; the DMA of the next one has landed
+    }
+    if (ktail) slab_product(nfull & 1, ktail, -1, (RAG && nfull == s0) ? kbeg - s0 * GBK : 0);
   }
-  if (ktail) slab_product(nfull & 1, ktail, -1);
   const int colb = n0 + wn * 64 + pta_mfma_col(l);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -455,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cv[j][r] = C[(int64_t)min(rowb + 4 * r, M - 1) * ldc + min(colb + j * 16, N - 1)];
+          cv[j][r] = C[(int64_t)min(RAG ? max(rowb + 4 * r, mbeg) : rowb + 4 * r, M - 1) * ldc + min(RAG ? max(colb + j * 16, nbeg) : colb + j * 16, N - 1)];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -464,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
         const int row = rowb + 4 * r, col = colb + j * 16;
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v = fma(beta, cv[j][r], v);
-        if (row < M && col < N && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
+        if (row < M && col < N && (!RAG || (row >= mbeg && col >= nbeg)) && (!lower_only || col <= row)) C[(int64_t)row * ldc + col] = v;
       }
   }
 }
@@ -518,7 +569,8 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
     const bool vec = transB && ska == 1 && (K % 2) == 0 && (lda % 2) == 0 && (ldb % 2) == 0 && (sA % 2) == 0 && (sB % 2) == 0 &&
                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
     if (vec && algo == 2)
-      hipLaunchKernelGGL(k_dgemm_glds128, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+      hipLaunchKernelGGL(k_dgemm_glds128<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, sA, sB, sC,
+                         pta_rag{nullptr, nullptr, nullptr}, 0, 0, 0, 0);
     else if (vec)
       hipLaunchKernelGGL((k_dgemm_mfma128<true, true>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else if (transB)
@@ -532,6 +584,34 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
       hipLaunchKernelGGL(k_dgemm_mfma<true>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else
       hipLaunchKernelGGL(k_dgemm_mfma<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
+  }
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+int pta_dgemm_launch_rag(int M, int N, int K, double alpha, double *Abase, int r0, int c0, int k0, const double *Bws, int64_t ldb, int64_t sB,
+                         double beta, int lower_only, int batch, pta_rag rg, hipStream_t stream) {
+  PTA_REQUIRE(Abase && rg.off && rg.ld && rg.front, PTA_E_ARG, "pta_dgemm_rag: NULL argument");
+  PTA_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, PTA_E_ARG, "pta_dgemm_rag: M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  PTA_REQUIRE(!(r0 & 1) && !(c0 & 1) && !(k0 & 1) && !(K & 1) && !(ldb & 1) && !(sB & 1) && ((uintptr_t)Abase % 16) == 0 && ((uintptr_t)Bws % 16) == 0,
+              PTA_E_ARG, "pta_dgemm_rag: origins, K and the workspace operand must be even / 16-byte aligned");
+  const double *B = Bws ? Bws : Abase;
+  const int bws = Bws ? 1 : 0;
+  if (M >= 256 && N >= 128 && K >= 32) {
+    PTA_REQUIRE(pta_cdiv(M, HBM_T) <= 65535u, PTA_E_ARG, "pta_dgemm_rag: M=%d too large", M);
+    dim3 g(pta_cdiv(N, HBM_T), pta_cdiv(M, HBM_T), batch);
+    if (lower_only && M == N) {
+      const unsigned nt = pta_cdiv(M, HBM_T);
+      g = dim3(nt * (nt + 1) / 2, 1, batch);
+      lower_only = 2;
+    }
+    hipLaunchKernelGGL(k_dgemm_glds128<true>, g, dim3(256), 0, stream, M, N, K, alpha, Abase, (int64_t)0, B, ldb, beta, Abase, (int64_t)0, lower_only,
+                       (int64_t)0, sB, (int64_t)0, rg, r0, c0, k0, bws);
+  } else {
+    PTA_REQUIRE(pta_cdiv(M, GBM) <= 65535u, PTA_E_ARG, "pta_dgemm_rag: M=%d too large", M);
+    dim3 g(pta_cdiv(N, GBN), pta_cdiv(M, GBM), batch);
+    hipLaunchKernelGGL((k_dgemm_mfma<true, true>), g, dim3(256), 0, stream, M, N, K, alpha, Abase, (int64_t)0, (int64_t)1, B, ldb, beta, Abase, (int64_t)0,
+                       lower_only, (int64_t)0, sB, (int64_t)0, rg, r0, c0, k0, bws);
   }
   PTA_LAUNCH_CHECK();
   return PTA_OK;

@@ -518,13 +518,34 @@ __global__ __launch_bounds__(256) void k_inv_blocks(const double *__restrict__ A
 // the rows of the block) and a share of k_inv_blocks: the two 64-step sweeps stay (registers of 256 threads, one barrier per pivot),
 // what lies between them - L21 = A21 X1^T, A22 -= L21 L21^T, the inverse's off-diagonal block - is 64 x 64 x 64 products on the
 // matrix cores out of LDS.  The tiles leave as k_potf2 leaves them (L below the diagonal, X^T parked above it).
+// RAG (ragged batch, end-aligned virtual coordinates - pta_common.h: pta_rag): the block starts at max(c0, front[b]); a matrix whose
+// front lies behind the block leaves at once, one whose front lies inside it factors the part it has and parks the inverse in the
+// bottom-right corner of the slot (the K / column masks of the ragged products never look at the rest); `idx` maps the chain position to
+// the caller's matrix index (info) and pivots are reported in the matrix's own numbering.
+template <bool RAG>
 __global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t lda, int64_t sA, int c0, int wd, double *__restrict__ W,
-                                                 int64_t ldw, int64_t sW, int32_t *__restrict__ info) {
+                                                 int64_t ldw, int64_t sW, int32_t *__restrict__ info, pta_rag rg, const int64_t *__restrict__ idx) {
   __shared__ double T11[64][65], T21[64][65], T22[64][65], TT[64][65];
   __shared__ double colbuf[2][CH_NB];
+  double *M, *Wb;
+  int32_t *info_b;
+  int col0;
+  if (RAG) {
+    const int f = (int)rg.front[blockIdx.x], cs = max(c0, f);
+    wd = c0 + wd - cs;
+    if (wd <= 0) return;
+    lda = rg.ld[blockIdx.x];
+    M = A + rg.off[blockIdx.x] + (int64_t)cs * lda + cs;
+    Wb = W + (int64_t)blockIdx.x * sW + (int64_t)(cs - c0) * ldw + (cs - c0);  // the part the matrix has: bottom-right corner of the slot
+    info_b = info + idx[blockIdx.x];
+    col0 = cs - f;
+  } else {
+    M = A + (int64_t)blockIdx.x * sA + (int64_t)c0 * lda + c0;
+    Wb = W + (int64_t)blockIdx.x * sW;  // the block's slot (the caller passes W already offset to strip j, column oj)
+    info_b = info + blockIdx.x;
+    col0 = c0;
+  }
   const int w1 = wd > 64 ? wd - 64 : wd, w2 = wd - w1;
-  double *M = A + (int64_t)blockIdx.x * sA + (int64_t)c0 * lda + c0;
-  double *Wb = W + (int64_t)blockIdx.x * sW;  // the block's slot (the caller passes W already offset to strip j, column oj)
   const int t = threadIdx.x, ti = t >> 4, tc = t & 15;
   const int l = t & 63, wv = t >> 6, li = l & 15, lq = l >> 4;
   double v[4][4];
@@ -561,7 +582,7 @@ __global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t
       const int p = ti + 16 * a, q = tc + 16 * b;
       v[a][b] = (p < w1 && q <= p) ? v[a][b] : 0.0;
     }
-  pta_potf2_sweep(v, colbuf, w1, ti, tc, info + blockIdx.x, c0);
+  pta_potf2_sweep(v, colbuf, w1, ti, tc, info_b, col0);
   // tile 1 -> global as it is (L, X1^T parked above the diagonal) and -> LDS as XS[k][c] = X1[c][k]: the part above the diagonal
   // as it is, 1 / L on the diagonal, zero below
 #pragma unroll
@@ -612,7 +633,7 @@ __global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t
         v[a][b] = q <= p ? T22[p][q] : 0.0;
       }
     __syncthreads();  // colbuf: the first sweep's last column has been read by everybody
-    pta_potf2_sweep(v, colbuf, 64, ti, tc, info + blockIdx.x, c0 + w1);
+    pta_potf2_sweep(v, colbuf, 64, ti, tc, info_b, col0 + w1);
     double *M2 = M + (int64_t)w1 * lda;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -662,7 +683,7 @@ __global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t
         x = c < w1 ? T11[c][r] : 0.0;
       else if (r < wd && c >= w1 && c < wd)
         x = T22[c - w1][r - w1];
-      if (!(w2 && r >= w1 && r < wd && c < w1)) Wb[(int64_t)r * ldw + c] = x;
+      if (!(w2 && r >= w1 && r < wd && c < w1) && (!RAG || (r < wd && c < wd))) Wb[(int64_t)r * ldw + c] = x;
     }
   }
   if (w2) {
@@ -683,8 +704,11 @@ __global__ __launch_bounds__(256) void k_diag128(double *__restrict__ A, int64_t
 // walks).  W_jj is lower triangular: the 16-row block b needs m < 16 (b + 1) only, i.e. its first 4 (b + 1) steps; a wave takes the
 // blocks w and 7 - w (36 of the 64 block-steps, the same for every wave).
 #define PTA_WS_STRIP_GROUP 4
+// RAG: a matrix whose (panel-relative) front fp lies at or behind the block has no left part and leaves; chunks wholly below fp are
+// skipped, the chunk that straddles it loads from clamped columns and stores only columns >= fp.
+template <bool RAG>
 __global__ __launch_bounds__(256) void k_ws_strips(const double *__restrict__ A, int64_t lda, int64_t sA, int k0, int f128, double *__restrict__ W,
-                                                   int64_t ldw, int64_t sW) {
+                                                   int64_t ldw, int64_t sW, pta_rag rg) {
   __shared__ double Bs[128][64];
   int g = blockIdx.x, j = 1, oj = f128;
   for (;;) {  // group -> (block j, group inside its chunks)
@@ -694,16 +718,26 @@ __global__ __launch_bounds__(256) void k_ws_strips(const double *__restrict__ A,
     ++j;
     oj += 128;
   }
+  int fp = 0;
+  if (RAG) {
+    fp = max(0, (int)rg.front[blockIdx.y] - k0);
+    if (fp >= oj || 64 * min((oj + 63) >> 6, (g + 1) * PTA_WS_STRIP_GROUP) <= fp) return;  // workgroup-uniform
+    lda = rg.ld[blockIdx.y];
+    A += rg.off[blockIdx.y];
+  } else {
+    A += (int64_t)blockIdx.y * sA;
+  }
   double *S = W + (int64_t)blockIdx.y * sW + (int64_t)j * 128 * ldw;
   const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), c = l & 15, q = l >> 4;
   typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));  // k0, oj may be odd: 8-byte alignment only
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   const int nch = (oj + 63) >> 6, ch0 = g * PTA_WS_STRIP_GROUP, ch1 = min(nch, ch0 + PTA_WS_STRIP_GROUP);
   // chunk rows oj .. oj + 127 of L11, columns c0 .. c0 + 63 (columns past oj are the block's own: valid memory, products not stored)
-  const double *Lrow = A + (int64_t)blockIdx.y * sA + (int64_t)(k0 + oj + (t >> 5)) * lda + k0 + 2 * (t & 31);
+  const double *Lrow = A + (int64_t)(k0 + oj + (t >> 5)) * lda + k0;
+  const int lc = 2 * (t & 31);  // column of this thread's pair inside a chunk
   f64x2_a8 pre[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + 64 * ch0);
+  for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + (RAG ? max(64 * ch0 + lc, fp) : 64 * ch0 + lc));
   const int blo = w, bhi = 7 - w;                      // the wave's two 16-row blocks
   const int ulo = 2 * (blo + 1), uhi = 2 * (bhi + 1);  // 8-column groups of W_jj they reach into
   const double *alo = S + oj + (int64_t)(16 * blo + c) * ldw + 2 * q, *ahi = S + oj + (int64_t)(16 * bhi + c) * ldw + 2 * q;
@@ -721,7 +755,7 @@ __global__ __launch_bounds__(256) void k_ws_strips(const double *__restrict__ A,
     __syncthreads();
     if (ch + 1 < ch1) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + 64 * (ch + 1));
+      for (int i = 0; i < 16; ++i) pre[i] = *reinterpret_cast<const f64x2_a8 *>(Lrow + (int64_t)(8 * i) * lda + (RAG ? max(64 * (ch + 1) + lc, fp) : 64 * (ch + 1) + lc));
     }
     pta_f64x4 acc[2][4];
 #pragma unroll
@@ -762,7 +796,7 @@ __global__ __launch_bounds__(256) void k_ws_strips(const double *__restrict__ A,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * (rb ? bhi : blo) + pta_mfma_row(l, r), col = c0 + 16 * cb + pta_mfma_col(l);
-          if (col < oj) S[(int64_t)row * ldw + col] = -acc[rb][cb][r];
+          if (col < oj && (!RAG || col >= fp)) S[(int64_t)row * ldw + col] = -acc[rb][cb][r];
         }
   }
 }
@@ -820,7 +854,7 @@ static int pta_factor_diag_ws(double *A, int pend, int64_t lda, int64_t sA, int 
     const int oj = c0 - p.k0;                                   // offset inside the panel: 0 for the first block, f128 + 128 (j - 1) after
     const int j = oj == 0 ? 0 : (oj - p.f128) / 128 + 1;
     double *Wjj = W + (int64_t)j * 128 * ldw + oj;
-    hipLaunchKernelGGL(k_diag128, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, Wjj, ldw, sW, info);
+    hipLaunchKernelGGL(k_diag128<false>, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, Wjj, ldw, sW, info, pta_rag{nullptr, nullptr, nullptr}, nullptr);
     PTA_LAUNCH_CHECK();
     const int rows = pend - c0 - w;
     if (rows <= 0) return PTA_OK;
@@ -856,7 +890,7 @@ static int pta_ws_diag_phase(double *A, int64_t lda, int64_t strideA, int B, int
   if (p.nb > 1) {
     int groups = 0;
     for (int j = 1; j < p.nb; ++j) groups += ((p.f128 + 128 * (j - 1) + 63) / 64 + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
-    hipLaunchKernelGGL(k_ws_strips, dim3(groups, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.f128, W, ldw, sW);
+    hipLaunchKernelGGL(k_ws_strips<false>, dim3(groups, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.f128, W, ldw, sW, pta_rag{nullptr, nullptr, nullptr});
     PTA_LAUNCH_CHECK();
   }
   return PTA_OK;
@@ -1043,6 +1077,232 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
     PTA_LAUNCH_CHECK();
   }
   return PTA_OK;
+}
+
+// ================================================================================================================================
+// Ragged batches: matrices of DIFFERENT orders as ONE schedule (pta_potrf_ragged).
+//
+// A real pulsar timing array has as many TOA counts as pulsars (noise_dicts/ng15_dict.json: 68 pulsars, 68 different N_a;
+// test_partim: 7758 / 23023 / 35037), and the reference handles that by construction - it loops over pulsars
+// (red_noise.py:286-298).  Batching by equal order would run such an array as 68 batches of ONE: one workgroup in every
+// diagonal-phase kernel on a 256-CU chip and a latency chain per matrix.  Instead the matrices are END-ALIGNED: embedded in a
+// virtual matrix of order E = NBO (Tmax + 1) whose bottom-right corner they share (virtual index = real index + front[b],
+// front[b] = E - n[b]).  Time step T = Tmax ... 0 factors the virtual panel [E - NBO (T + 1), E - NBO T): for every matrix that has
+// reached it (n[b] > NBO T - a prefix of the batch sorted by decreasing order) panel boundaries, the trailing size NBO T and all
+// tile grids are the SAME, so every kernel of the step is one launch over the active prefix; a matrix ENTERS at the step that
+// contains its first column with a panel cut at its front, which the kernels mask (pta_rag: k_diag128<true>, k_ws_strips<true>,
+// the ragged tile products).  Cost: the diagonal phases - the latency chains - are paid once per TIME STEP instead of once per
+// matrix and panel; the tile products of a step cover all active matrices.  Uniform batches are the special case front[b] = const.
+// Orders, offsets and leading dimensions must be even (16-byte operand rows; pad an odd order with an identity row / column at its end).
+// ================================================================================================================================
+#define PTA_RAG_MAGIC 0x5054415241474544LL
+#define PTA_RAG_HDR 8
+#define PTA_RAG_CHDR 8
+
+struct pta_rag_chain {
+  double *A;
+  pta_rag rg;            // device arrays of this chain, sorted by decreasing order
+  const int64_t *idx;    // device: caller's index of chain position
+  const int64_t *n;      // HOST: orders, decreasing
+  int Bc, E, Tmax, NBO;
+  double *W;
+  int64_t ldw, sW;
+  int32_t *info;
+};
+
+static inline int pta_rag_active(const pta_rag_chain &c, int T) {  // matrices that have reached time step T: n > NBO T (a prefix)
+  int b = 0;
+  while (b < c.Bc && c.n[b] > (int64_t)c.NBO * T) ++b;
+  return b;
+}
+
+// X <- [X_{<j} | B_j] S^T on `rows` rows from virtual row rv: block columns [cblk, cblk + wj), kl columns to their left prepended to the
+// K range, S = the strip (its column kl <-> virtual column cblk).  One column tile per launch, right to left (in place).
+static int pta_rag_apply_block(const pta_rag_chain &c, int B, int rv, int rows, int cblk, int wj, int kl, const double *S, hipStream_t s) {
+  const int tile = pta_dgemm_tile_n(rows, wj, kl + wj, 2);
+  for (int c1 = wj; c1 > 0; c1 -= tile) {
+    const int c0 = c1 > tile ? c1 - tile : 0;
+    int rc = pta_dgemm_launch_rag(rows, c1 - c0, kl + c1, 1.0, c.A, rv, cblk + c0, cblk - kl, S + (int64_t)c0 * c.ldw, c.ldw, c.sW, 0.0, 0, B, c.rg, s);
+    if (rc != PTA_OK) return rc;
+  }
+  return PTA_OK;
+}
+
+// the recursion of pta_factor_diag_ws in virtual coordinates: diagonal block [k0, pend) of the panel, columns [c0, c0 + w)
+static int pta_rag_factor_diag(const pta_rag_chain &c, int B, int k0, int pend, int c0, int w, hipStream_t sp) {
+  if (w <= 128) {
+    const int oj = c0 - k0, j = oj / 128;
+    double *Wjj = c.W + (int64_t)j * 128 * c.ldw + oj;
+    hipLaunchKernelGGL(k_diag128<true>, dim3(B), dim3(256), 0, sp, c.A, (int64_t)0, (int64_t)0, c0, w, Wjj, c.ldw, c.sW, c.info, c.rg, c.idx);
+    PTA_LAUNCH_CHECK();
+    const int rows = pend - c0 - w;
+    if (rows <= 0) return PTA_OK;
+    return pta_rag_apply_block(c, B, c0 + w, rows, c0, w, 0, Wjj, sp);
+  }
+  int cols = (w / 2 / 128) * 128;
+  if (cols < 128) cols = 128;
+  const int w1 = w - cols;
+  int rc = pta_rag_factor_diag(c, B, k0, pend, c0, w1, sp);
+  if (rc != PTA_OK) return rc;
+  const int rows = pend - (c0 + w1);
+  rc = pta_dgemm_launch_rag(rows, cols, w1, -1.0, c.A, c0 + w1, c0 + w1, c0, nullptr, 0, 0, 1.0, 1, B, c.rg, sp);
+  if (rc != PTA_OK) return rc;
+  return pta_rag_factor_diag(c, B, k0, pend, c0 + w1, cols, sp);
+}
+
+static int pta_rag_diag_phase(const pta_rag_chain &c, int T, int B, hipStream_t s) {
+  const int k0 = c.E - c.NBO * (T + 1), pend = k0 + c.NBO;
+  int rc = pta_rag_factor_diag(c, B, k0, pend, k0, c.NBO, s);
+  if (rc != PTA_OK || T == 0) return rc;  // the last panel: nothing below it needs the strips
+  const int nb = c.NBO / 128;
+  int groups = 0;
+  for (int j = 1; j < nb; ++j) groups += ((128 * j + 63) / 64 + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
+  hipLaunchKernelGGL(k_ws_strips<true>, dim3(groups, B), dim3(256), 0, s, c.A, (int64_t)0, (int64_t)0, k0, 128, c.W, c.ldw, c.sW, c.rg);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
+static int pta_rag_solve_phase(const pta_rag_chain &c, int T, int B, hipStream_t s) {
+  const int k0 = c.E - c.NBO * (T + 1), pend = k0 + c.NBO, rows = c.NBO * T, nb = c.NBO / 128;
+  for (int j = 0; j < nb; ++j) {
+    int rc = pta_rag_apply_block(c, B, pend, rows, k0 + 128 * j, 128, 128 * j, c.W + (int64_t)j * 128 * c.ldw, s);
+    if (rc != PTA_OK) return rc;
+  }
+  return PTA_OK;
+}
+
+// one chain, all time steps; `side` != nullptr: the next panel's diagonal phase runs ahead beside the bulk of the trailing update
+// (as pta_potrf_chain_ws_lookahead; the phase of step T - 1 also covers the matrices that enter there)
+static int pta_rag_chain_run(const pta_rag_chain &c, hipStream_t s, hipStream_t side, hipEvent_t ev_u1, hipEvent_t ev_la) {
+  int T = c.Tmax, B = pta_rag_active(c, T);
+  int rc = pta_rag_diag_phase(c, T, B, s);
+  if (rc != PTA_OK) return rc;
+  bool joined = true;
+  while (T > 0) {
+    if ((rc = pta_rag_solve_phase(c, T, B, s)) != PTA_OK) break;
+    const int k0 = c.E - c.NBO * (T + 1), pend = k0 + c.NBO, Tq = T - 1, Bq = pta_rag_active(c, Tq), rows_q = c.NBO * Tq;
+    // U1: the next panel's diagonal block
+    if ((rc = pta_dgemm_launch_rag(c.NBO, c.NBO, c.NBO, -1.0, c.A, pend, pend, k0, nullptr, 0, 0, 1.0, 1, B, c.rg, s)) != PTA_OK) break;
+    const bool la = side != nullptr && rows_q >= PTA_WS_LA_MIN_ROWS;
+    if (la) {
+      if (hipEventRecord(ev_u1, s) != hipSuccess || hipStreamWaitEvent(side, ev_u1, 0) != hipSuccess) { rc = PTA_E_HIP; break; }
+      joined = false;
+      rc = pta_rag_diag_phase(c, Tq, Bq, side);
+      (void)hipEventRecord(ev_la, side);
+      if (rc != PTA_OK) break;
+    }
+    if (rows_q > 0) {
+      // U2: the rows below the next panel - its sub-diagonal rectangle and the lower triangle behind it
+      if ((rc = pta_dgemm_launch_rag(rows_q, c.NBO, c.NBO, -1.0, c.A, pend + c.NBO, pend, k0, nullptr, 0, 0, 1.0, 0, B, c.rg, s)) != PTA_OK) break;
+      if ((rc = pta_dgemm_launch_rag(rows_q, rows_q, c.NBO, -1.0, c.A, pend + c.NBO, pend + c.NBO, k0, nullptr, 0, 0, 1.0, 1, B, c.rg, s)) != PTA_OK) break;
+    }
+    if (la) {
+      (void)hipStreamWaitEvent(s, ev_la, 0);
+      joined = true;
+    } else if ((rc = pta_rag_diag_phase(c, Tq, Bq, s)) != PTA_OK) {
+      break;
+    }
+    T = Tq;
+    B = Bq;
+  }
+  if (!joined) (void)hipStreamWaitEvent(s, ev_la, 0);
+  return rc;
+}
+
+extern "C" int64_t pta_potrf_ragged_plan_words(int B) { return B > 0 ? PTA_RAG_HDR + PTA_RAG_CHDR * PTA_POTRF_MAX_CHAINS + 5 * (int64_t)B : 0; }
+
+extern "C" int pta_potrf_ragged_plan(const int32_t *n, const int64_t *off, const int64_t *ld, int B, int flags, int64_t *plan, int64_t *work_doubles) {
+  PTA_REQUIRE(n && off && ld && plan && work_doubles, PTA_E_ARG, "pta_potrf_ragged_plan: NULL argument");
+  PTA_REQUIRE(B > 0 && B <= 65535, PTA_E_ARG, "pta_potrf_ragged_plan: B=%d", B);
+  PTA_REQUIRE(!(flags & (PTA_POTRF_VALU | PTA_POTRF_SUBSTITUTION | PTA_POTRF_REG_STAGING | PTA_POTRF_DIAG64 | PTA_POTRF_ZERO_UPPER)), PTA_E_ARG,
+              "pta_potrf_ragged_plan: flags 0x%x not supported by the ragged schedule (chains, panel width and NO_LOOKAHEAD are)", flags);
+  for (int b = 0; b < B; ++b)
+    PTA_REQUIRE(n[b] >= 2 && n[b] <= (1 << 20) && !(n[b] & 1) && !(off[b] & 1) && !(ld[b] & 1) && ld[b] >= n[b] && off[b] >= 0, PTA_E_ARG,
+                "pta_potrf_ragged_plan: matrix %d: n=%d off=%lld ld=%lld (even order / offset / leading dimension needed, ld >= n)", b, n[b],
+                (long long)off[b], (long long)ld[b]);
+  const int nbk = (flags >> 8) & 0xFF;
+  const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;   // panel width: 1024 unless overridden (PTA_POTRF_NB(k): 256 k)
+  int nchain = (flags >> 16) & 0xF;
+  if (nchain == 0) nchain = 2;
+  if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
+  if (nchain > B) nchain = B;
+  if (flags & PTA_POTRF_NO_LOOKAHEAD) nchain = 1;
+  // matrices sorted by decreasing order (ties: caller's order) and dealt to the chains in turn, so that every chain gets the same
+  // mix of orders and its active set is a prefix at every time step
+  int *order = (int *)malloc(sizeof(int) * (size_t)B);
+  PTA_REQUIRE(order, PTA_E_ARG, "pta_potrf_ragged_plan: out of host memory");
+  for (int b = 0; b < B; ++b) order[b] = b;
+  for (int i = 1; i < B; ++i) {  // insertion sort, stable (B is a pulsar count)
+    const int v = order[i];
+    int k = i;
+    while (k > 0 && n[order[k - 1]] < n[v]) order[k] = order[k - 1], --k;
+    order[k] = v;
+  }
+  const int64_t ldw = NBO, sW = ldw * ldw;
+  int64_t words = PTA_RAG_HDR + PTA_RAG_CHDR * PTA_POTRF_MAX_CHAINS, wdoubles = 0;
+  for (int c = 0; c < nchain; ++c) {
+    const int Bc = (B - c + nchain - 1) / nchain;
+    int64_t *h = plan + PTA_RAG_HDR + PTA_RAG_CHDR * c;
+    const int nmax = n[order[c]];
+    const int Tmax = (nmax - 1) / NBO, E = NBO * (Tmax + 1);
+    h[0] = Bc, h[1] = E, h[2] = Tmax, h[3] = words, h[4] = wdoubles, h[5] = h[6] = h[7] = 0;
+    int64_t *a_off = plan + words, *a_ld = a_off + Bc, *a_front = a_ld + Bc, *a_idx = a_front + Bc, *a_n = a_idx + Bc;
+    for (int k = 0; k < Bc; ++k) {
+      const int b = order[c + k * nchain];
+      const int64_t front = E - n[b];
+      a_off[k] = off[b] - front * (ld[b] + 1);
+      a_ld[k] = ld[b];
+      a_front[k] = front;
+      a_idx[k] = b;
+      a_n[k] = n[b];
+    }
+    words += 5 * (int64_t)Bc;
+    wdoubles += (int64_t)Bc * sW;
+  }
+  free(order);
+  plan[0] = PTA_RAG_MAGIC, plan[1] = B, plan[2] = flags, plan[3] = nchain, plan[4] = NBO, plan[5] = wdoubles, plan[6] = words, plan[7] = 0;
+  *work_doubles = wdoubles;
+  return PTA_OK;
+}
+
+extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *plan_dev, int32_t *info, double *work, int64_t work_doubles,
+                                void *stream) {
+  PTA_REQUIRE(A && plan && plan_dev && info && work, PTA_E_ARG, "pta_potrf_ragged: NULL argument");
+  PTA_REQUIRE(plan[0] == PTA_RAG_MAGIC, PTA_E_ARG, "pta_potrf_ragged: `plan` was not written by pta_potrf_ragged_plan");
+  PTA_REQUIRE(work_doubles >= plan[5], PTA_E_ARG, "pta_potrf_ragged: workspace of %lld doubles, %lld needed", (long long)work_doubles, (long long)plan[5]);
+  PTA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)work % 16) == 0, PTA_E_ARG, "pta_potrf_ragged: A and work must be 16-byte aligned");
+  const int B = (int)plan[1], flags = (int)plan[2], nchain = (int)plan[3], NBO = (int)plan[4];
+  hipStream_t s = pta_stream(stream);
+  PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
+  pta_potrf_ctx *cx = nullptr;
+  int rc = pta_potrf_ctx_get(&cx);
+  if (rc != PTA_OK) return rc;
+  const bool la = !(flags & PTA_POTRF_NO_LOOKAHEAD);
+  if (nchain > 1 || la) PTA_HIP(hipEventRecord(cx->ev_in, s));
+  int rc_chain = PTA_OK;
+  for (int c = 0; c < nchain && rc_chain == PTA_OK; ++c) {
+    const int64_t *h = plan + PTA_RAG_HDR + PTA_RAG_CHDR * c;
+    pta_rag_chain ch;
+    ch.A = A;
+    ch.Bc = (int)h[0], ch.E = (int)h[1], ch.Tmax = (int)h[2], ch.NBO = NBO;
+    const int64_t *d = plan_dev + h[3];
+    ch.rg = pta_rag{d, d + ch.Bc, d + 2 * ch.Bc};
+    ch.idx = d + 3 * ch.Bc;
+    ch.n = plan + h[3] + 4 * ch.Bc;
+    ch.W = work + h[4];
+    ch.ldw = NBO, ch.sW = (int64_t)NBO * NBO;
+    ch.info = info;
+    hipStream_t sc = nchain == 1 ? s : cx->chain[c];
+    if (nchain > 1) PTA_HIP(hipStreamWaitEvent(sc, cx->ev_in, 0));
+    if (la) PTA_HIP(hipStreamWaitEvent(cx->side[c], cx->ev_in, 0));
+    rc_chain = pta_rag_chain_run(ch, sc, la ? cx->side[c] : nullptr, cx->ev_u1[c], cx->ev_la[c]);
+  }
+  if (nchain > 1)
+    for (int c = 0; c < nchain; ++c) {  // join on every exit, error included
+      (void)hipEventRecord(cx->ev_out[c], cx->chain[c]);
+      (void)hipStreamWaitEvent(s, cx->ev_out[c], 0);
+    }
+  return rc_chain;
 }
 
 extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,

@@ -50,49 +50,23 @@ class TimeDomainMixin:
             self.prepare()
         if self._wn is None:
             raise ValueError("TD mode needs measurement noise (set_white_noise): without it the dense covariance is singular")
-        P, N = self.P, self.n_toa
-        s = dv.stream_ptr()
+        P = self.P
         pl = self.plan
         counts = [int(c) for c in self.counts]
-        ld = [(n + 15) // 16 * 16 for n in counts]        # rows start on 128-byte lines (and even: the product kernel loads double2)
-        pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(counts, ld)])]).astype(np.int64)
-        self.td_ld, self.td_pos = ld, pos
+        # storage order: an odd TOA count gets one identity row / column at its END (diag(C, 1) factors to diag(L, 1); the product
+        # kernel never reads it) so that every panel boundary of the end-aligned ragged factorisation falls on a 16-byte boundary
+        nst = [n + (n & 1) for n in counts]
+        ld = [(n + 15) // 16 * 16 for n in nst]           # rows start on 128-byte lines (and even: the product kernel loads double2)
+        pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(nst, ld)])]).astype(np.int64)
+        self.td_ld, self.td_pos, self.td_nst = ld, pos, nst
         self.d_Ltd = None                                  # release a previous factor buffer first: two do not fit at SKA scale
         self.d_Ltd = dv.empty((int(pos[-1]),))
         sigma2 = self.d_wn_a ** 2 + self.d_wn_b ** 2      # (efac sigma)^2 + (efac equad | equad)^2
         self._td_sigma2 = sigma2
-        K = pl.rn_k
-        phi = (self.d_amp ** 2).contiguous() if K else None
-        ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
-        # block layout arrays (also what the product kernel reads), then ONE assembly launch over all pulsars
+        # block layout arrays (also what the product kernel reads)
         self._td_layout = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1])]
-        _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(sigma2),
-                  dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
-                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
-        # batched factorisation: runs of consecutive pulsars with the same TOA count share one launch sequence
-        info = dv.zeros((P,), dtype=torch.int32)
-        # workspace scheme of the factorisation (include/pta_replicator_amd.h: pta_potrf_batched_ws): strips [-W_jj L11[j, <j] | W_jj] of
-        # the panels' diagonal blocks, 10.6 MB per matrix at the default panel width, released right after the factorisation - and
-        # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.2 ms against 56.5 ms
-        # without; td_potrf_workspace = False keeps the workspace-free two-chain schedule.
-        use_ws = bool(getattr(self, "td_potrf_workspace", True))
-        flags = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
-        flags |= int(getattr(self, "td_potrf_flags", 0))
-        a = 0
-        while a < P:
-            b = a
-            while b + 1 < P and counts[b + 1] == counts[a]:
-                b += 1
-            need = int(_lib.lib.pta_potrf_workspace_doubles(counts[a], b - a + 1, flags)) if use_ws else 0
-            work = dv.empty((need,)) if need else None
-            _lib.call("pta_potrf_batched_ws", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), counts[a], ld[a],
-                      counts[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, dv.ptr(work), need, s)
-            del work                                    # stream-ordered: the caching allocator reuses it only behind these kernels
-            a = b + 1
-        bad = info.cpu().numpy()
-        if np.any(bad != 0):
-            a = int(np.nonzero(bad)[0][0])
-            raise np.linalg.LinAlgError(f"TD covariance of {self.names[a]} is not positive definite (leading minor {int(bad[a])})")
+        self.td_assemble()
+        self.td_factorise(lookahead=lookahead)
         blk, n0 = _strips(counts)
         self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0)]
         tp = _lib.TdPlan()
@@ -112,6 +86,73 @@ class TimeDomainMixin:
         self._td_ws = None
         self._td_prepared = True
         return self
+
+    def td_assemble(self):
+        """ONE assembly launch over all pulsars: lower triangles of C_a into the factor buffer (+ the identity tail of odd orders)."""
+        pl, P, N, s = self.plan, self.P, self.n_toa, dv.stream_ptr()
+        counts = [int(c) for c in self.counts]
+        K = pl.rn_k
+        phi = (self.d_amp ** 2).contiguous() if K else None
+        ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
+        _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
+                  dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
+                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
+        for a, n in enumerate(counts):
+            if n & 1:
+                row = self.d_Ltd[int(self.td_pos[a]) + n * self.td_ld[a]: int(self.td_pos[a]) + n * self.td_ld[a] + n + 1]
+                row.zero_()
+                row[n] = 1.0
+
+    def td_factorise(self, lookahead=True, mode=None):
+        """the batched factorisation of the assembled covariances, in place.  mode (default: attribute td_potrf_mode, "auto"):
+        "uniform" = runs of consecutive pulsars with the same TOA count share one pta_potrf_batched_ws launch sequence (a real array
+        degenerates to batches of one); "ragged" = ALL pulsars as one end-aligned schedule (pta_potrf_ragged); "auto" = uniform when
+        every pulsar has the same count, ragged otherwise."""
+        P, s = self.P, dv.stream_ptr()
+        nst, ld, pos = self.td_nst, self.td_ld, self.td_pos
+        mode = mode or getattr(self, "td_potrf_mode", "auto")
+        if mode == "auto":
+            mode = "uniform" if len(set(nst)) == 1 else "ragged"
+        info = dv.zeros((P,), dtype=torch.int32)
+        extra = int(getattr(self, "td_potrf_flags", 0))
+        if mode == "ragged":
+            flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | extra
+            key = (tuple(nst), flags)
+            if getattr(self, "_td_rag_key", None) != key:
+                words = int(_lib.lib.pta_potrf_ragged_plan_words(P))
+                plan = np.zeros(words, dtype=np.int64)
+                need = ctypes.c_int64(0)
+                _lib.call("pta_potrf_ragged_plan", dv.hptr(np.asarray(nst, dtype=np.int32)), dv.hptr(np.asarray(pos[:-1], dtype=np.int64)),
+                          dv.hptr(np.asarray(ld, dtype=np.int64)), P, flags, dv.hptr(plan), ctypes.byref(need))
+                self._td_rag_plan, self._td_rag_plan_dev, self._td_rag_need, self._td_rag_key = plan, dv.i64(plan), int(need.value), key
+            work = dv.empty((self._td_rag_need,))
+            _lib.call("pta_potrf_ragged", dv.ptr(self.d_Ltd), dv.hptr(self._td_rag_plan), dv.ptr(self._td_rag_plan_dev), dv.ptr(info), dv.ptr(work),
+                      self._td_rag_need, s)
+            del work                                    # stream-ordered: the caching allocator reuses it only behind these kernels
+        else:
+            # workspace scheme of the factorisation (include/pta_replicator_amd.h: pta_potrf_batched_ws): strips [-W_jj L11[j, <j] | W_jj] of
+            # the panels' diagonal blocks, 10.6 MB per matrix at the default panel width, released right after the factorisation - and
+            # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.2 ms against 56.5 ms
+            # without (DESIGN.md §4.2); td_potrf_workspace = False keeps the workspace-free two-chain schedule.
+            use_ws = bool(getattr(self, "td_potrf_workspace", True))
+            flags = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
+            flags |= extra
+            a = 0
+            while a < P:
+                b = a
+                while b + 1 < P and nst[b + 1] == nst[a]:
+                    b += 1
+                need = int(_lib.lib.pta_potrf_workspace_doubles(nst[a], b - a + 1, flags)) if use_ws else 0
+                work = dv.empty((need,)) if need else None
+                _lib.call("pta_potrf_batched_ws", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), nst[a], ld[a],
+                          nst[a] * ld[a], b - a + 1, ctypes.c_void_p(info.data_ptr() + 4 * a), flags, dv.ptr(work), need, s)
+                del work
+                a = b + 1
+        self.td_potrf_mode_used = mode
+        bad = info.cpu().numpy()
+        if np.any(bad != 0):
+            a = int(np.nonzero(bad)[0][0])
+            raise np.linalg.LinAlgError(f"TD covariance of {self.names[a]} is not positive definite (leading minor {int(bad[a])})")
 
     def _prepare_gw_grid_factor(self):
         """Cholesky factor L_g of the covariance of the npts GWB grid samples of one pulsar, Sigma_g = T^T T (T the twiddle

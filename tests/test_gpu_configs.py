@@ -17,9 +17,10 @@ def _fused_equals_replay(eng, r):
     return out
 
 
-def test_config2_test_partim_set_per_backend_noise_256_realisations():
-    """B1855+09 (real tim: 7758 unsorted TOAs, 4 backends) + B1937+21 / J1909-3744 synthesised at their par-file
-    NTOA (23023 / 35037), per-backend EFAC/EQUAD/ECORR (coarsegrain 1 s as in notebook cell 9) + per-pulsar RN."""
+def _config2_engine(seed=222):
+    """BASELINE.json config 2: B1855+09 (the reference's real tim file: 7758 unsorted TOAs, 4 backends, multi-TOA 1 s epochs) +
+    B1937+21 / J1909-3744 synthesised at their par-file NTOA (23023 / 35037; test_partim/par/*.par:17), per-backend EFAC / EQUAD / ECORR
+    (coarsegrain 1 s as in notebook cell 9) + per-pulsar red noise."""
     from pta_replicator_amd.engine import ReplicaEngine
     from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
     z = load("c2_b1855.npz")
@@ -38,11 +39,19 @@ def test_config2_test_partim_set_per_backend_noise_256_realisations():
     for p in psrs:
         make_ideal(p)
     P = len(psrs)
-    eng = ReplicaEngine(psrs, seed=222)
+    eng = ReplicaEngine(psrs, seed=seed)
     eng.set_white_noise(efac=[z["efac"]] * P, log10_equad=[z["log10_equad"]] * P, flags=[list(z["efac_flags"])] * P)
     eng.set_jitter(log10_ecorr=[z["log10_ecorr"]] * P, flags=[list(z["ecorr_flags"])] * P, coarsegrain=1.0 / 86400.0)
     eng.set_red_noise([float(z["rn_log10_amp"]), -13.5, -14.2], [float(z["rn_gamma"]), 2.5, 4.0], components=30)
     eng.prepare()
+    return eng, psrs, z
+
+
+def test_config2_test_partim_set_per_backend_noise_256_realisations():
+    """B1855+09 (real tim: 7758 unsorted TOAs, 4 backends) + B1937+21 / J1909-3744 synthesised at their par-file
+    NTOA (23023 / 35037), per-backend EFAC/EQUAD/ECORR (coarsegrain 1 s as in notebook cell 9) + per-pulsar RN."""
+    eng, psrs, z = _config2_engine()
+    P = len(psrs)
     assert eng.n_toa == 7758 + 23023 + 35037
     out = eng.generate(256).cpu().numpy()
     assert out.shape == (256, eng.n_toa) and np.all(np.isfinite(out))
@@ -71,6 +80,65 @@ def test_config2_test_partim_set_per_backend_noise_256_realisations():
     white = out[:8, sel] - rn_part
     expect = np.mean((z["efac"][k] * eng.sigma_s[0][sel]) ** 2 + (z["efac"][k] * 10 ** z["log10_equad"][k]) ** 2) + (10 ** z["log10_ecorr"][kj]) ** 2
     assert abs(np.var(white) / expect - 1) < 0.15
+
+
+def test_config2_td_mode():
+    """BASELINE.json config 2 ("batched Cholesky bring-up") through the DENSE path: the real unsorted 4-backend B1855+09 (its same-epoch
+    ECORR blocks are scattered through the matrix) and the 23023- / 35037-TOA pulsars - three different orders (one of them odd twice
+    over), factored as ONE ragged schedule (pta_potrf_ragged).  Per pulsar, 64 sampled rows i: (L L^T)[i, :] against the oracle's covariance
+    row (oracle/pta_oracle.py: td_covariance_rows) at 1e-12 ||C||_max; the whole 7758^2 factor against LAPACK; generate_td(256) finite;
+    L z of the dumped deviates on those rows at 1e-10; memory-draw == register-draw; ragged == per-matrix schedule."""
+    import torch
+    eng, psrs, z = _config2_engine(seed=223)
+    P = len(psrs)
+    eng.td_potrf_mode = "ragged"
+    eng.prepare_td()
+    assert eng.td_potrf_mode_used == "ragged"
+    rn_par = [(float(z["rn_log10_amp"]), float(z["rn_gamma"])), (-13.5, 2.5), (-14.2, 4.0)]
+    rng = np.random.default_rng(64)
+    R = 256
+    eng.td_draws = "memory"
+    out = eng.generate_td(R, r0=5)
+    assert bool(torch.isfinite(out).all())
+    eng.td_draws = "registers"
+    assert torch.equal(eng.generate_td(4, r0=5), out[:4])           # the same deviates generated inside the product: bit-identical
+    eng.td_draws = "memory"
+    draws = eng.dump_draws_td(7)
+    got7 = out[2].cpu().numpy()
+    rows_of = {}
+    for a in range(P):
+        n = int(eng.counts[a])
+        tfa = np.array([f["f"] for f in psrs[a].toas.flags])
+        sigma2 = (po.flag_vector(tfa, z["efac_flags"], z["efac"], n) * eng.sigma_s[a]) ** 2 + \
+                 (po.flag_vector(tfa, z["efac_flags"], z["efac"], n) * po.flag_vector(tfa, z["efac_flags"], 10 ** z["log10_equad"], n)) ** 2
+        epoch_of, ne, first, _ = po.quantize(eng.mjd[a], tfa, dt=1.0 / 86400.0)
+        ecv = po.jitter_ecorr_vector(ne, first, z["log10_ecorr"], tfa, z["ecorr_flags"])
+        rows = np.unique(np.concatenate([[0, 1, n // 2, n - 2, n - 1], rng.integers(0, n, 64)]))
+        rows_of[a] = rows
+        Cref = po.td_covariance_rows(eng.tdb_s[a], rn_par[a][0], rn_par[a][1], 30, sigma2, epoch_of, ecv, rows)
+        L = eng.td_factor(a)                                          # device copy, upper triangle zeroed
+        ridx = torch.as_tensor(rows, device=L.device)
+        Lr = L[ridx]
+        LLt = (Lr @ L.T).cpu().numpy()
+        scale = np.max(np.abs(np.diag(Cref[:, rows])))
+        assert np.max(np.abs(LLt - Cref)) < 1e-12 * scale, (a, np.max(np.abs(LLt - Cref)) / scale)
+        # L z on the sampled rows (NumPy on the copied-back rows of the device factor)
+        ref = Lr.cpu().numpy() @ draws["td"][a]
+        sl = slice(int(eng.off[a]), int(eng.off[a + 1]))
+        assert np.max(np.abs(got7[sl][rows] - ref)) < 1e-10 * np.sqrt(np.mean(ref ** 2)), a
+        if a == 0:   # the real tim file's pulsar: the whole factor against LAPACK
+            Cfull = po.td_covariance(eng.tdb_s[a], rn_par[a][0], rn_par[a][1], 30, sigma2, epoch_of, ecv)
+            Lref = np.linalg.cholesky(Cfull)
+            Ld = L.cpu().numpy()
+            assert np.max(np.abs(Ld - Lref)) < 1e-10 * np.max(np.abs(Lref))
+        del L, Lr
+    # the per-matrix schedule (batches of one) gives the same factors
+    fr = {a: eng.td_factor(a)[torch.as_tensor(rows_of[a], device="cuda")].cpu().numpy() for a in range(P)}
+    eng.td_assemble()
+    eng.td_factorise(mode="uniform")
+    for a in range(P):
+        fu = eng.td_factor(a)[torch.as_tensor(rows_of[a], device="cuda")].cpu().numpy()
+        assert np.max(np.abs(fu - fr[a])) < 1e-11 * np.max(np.abs(fu)), a
 
 
 def test_config4_headline_array_with_cgw():

@@ -262,6 +262,100 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     assert int(lib.lib.pta_potrf_workspace_doubles(n, batch, fl | lib.POTRF_SUBSTITUTION)) == 0
 
 
+def _ragged_factor(gpu, mats, flags, nan_upper=True):
+    """pta_potrf_ragged on a list of SPD matrices (any even orders): returns the lower factors and info."""
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    B = len(mats)
+    n = np.array([m.shape[0] for m in mats], dtype=np.int32)
+    ld = ((n.astype(np.int64) + 15) // 16 * 16 + 16 * (np.arange(B) % 2)).astype(np.int64)     # some slack in every other matrix
+    off = np.concatenate([[0], np.cumsum(n.astype(np.int64) * ld + 32)])[:-1].astype(np.int64)    # and between matrices
+    buf = np.full(int(off[-1] + n[-1] * ld[-1] + 32), np.nan)
+    for b, m in enumerate(mats):
+        v = buf[off[b]:off[b] + n[b] * ld[b]].reshape(n[b], ld[b])
+        v[:, :n[b]] = np.tril(m) + (np.triu(np.full(m.shape, np.nan), 1) if nan_upper else np.triu(m, 1))
+    Ad = dv.f64(buf)
+    words = int(lib.lib.pta_potrf_ragged_plan_words(B))
+    plan = np.zeros(words, dtype=np.int64)
+    need = ctypes.c_int64(0)
+    lib.call("pta_potrf_ragged_plan", dv.hptr(n), dv.hptr(off), dv.hptr(ld), B, flags, dv.hptr(plan), ctypes.byref(need))
+    work = dv.empty((need.value,))
+    work.fill_(float("nan"))
+    info = dv.zeros((B,), dtype=torch.int32)
+    plan_d = dv.i64(plan)
+    lib.call("pta_potrf_ragged", dv.ptr(Ad), dv.hptr(plan), dv.ptr(plan_d), dv.ptr(info), dv.ptr(work), need.value, gpu["s"])
+    out = Ad.cpu().numpy()
+    Ls = [np.tril(out[off[b]:off[b] + n[b] * ld[b]].reshape(n[b], ld[b])[:, :n[b]]) for b in range(B)]
+    return Ls, info.cpu().numpy()
+
+
+def _spd(rng, n):
+    X = rng.standard_normal((n, n + 5))
+    return X @ X.T + 0.1 * np.eye(n)
+
+
+@pytest.mark.parametrize("orders,flags", [
+    ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), 0),          # two chains, look-ahead, 1024-column panels: entries at every kind of cut
+    ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), "C1"),
+    ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), "NOLA"),
+    ((1500, 258, 700, 256, 254, 1280, 1282, 66, 1024, 512, 130), "NB1"),  # 256-column panels: many time steps, matrices entering at most of them
+    ((1500, 258, 700, 256, 254, 1280, 1282, 66, 1024, 512, 130), "NB1C3"),
+    ((2200, 2200, 2200), "NB1"),                                           # a uniform batch is the special case front = const
+    ((4200, 3100, 600), "NB2"),
+    ((5000,), 0),                                                           # a batch of one
+])
+def test_potrf_ragged_vs_numpy(gpu, orders, flags):
+    """pta_potrf_ragged: matrices of different orders as ONE end-aligned schedule (red_noise.py:286-298 loops pulsars; a real array has
+    as many TOA counts as pulsars) against LAPACK - NaN above every diagonal, NaN-filled workspace, leading-dimension and inter-matrix
+    slack; orders that enter a time step at a block boundary, inside a block, one column before / after a panel boundary, and
+    matrices smaller than one block."""
+    lib = gpu["lib"]
+    fl = {0: 0, "C1": lib.POTRF_CHAINS(1), "NOLA": lib.POTRF_NO_LOOKAHEAD, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3),
+          "NB2": lib.POTRF_NB(2)}[flags]
+    rng = np.random.default_rng(sum(orders))
+    mats = [_spd(rng, n) for n in orders]
+    Ls, info = _ragged_factor(gpu, mats, fl)
+    assert not info.any(), info
+    for b, (L, m) in enumerate(zip(Ls, mats)):
+        ref = np.linalg.cholesky(m)
+        assert np.all(np.isfinite(L)), (b, orders[b])
+        assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (b, orders[b], flags)
+
+
+def test_potrf_ragged_reports_the_first_bad_pivot_of_the_right_matrix(gpu):
+    """info[b] in the caller's order and in the matrix's own numbering (LAPACK convention), whatever chain / time step the pivot falls in."""
+    rng = np.random.default_rng(5)
+    orders = (1400, 300, 2300, 700)
+    mats = [_spd(rng, n) for n in orders]
+    mats[2][1500:, 1500:] -= 2.0 * np.diag(np.diag(mats[2][1500:, 1500:]))   # Schur complement negative from row 1500 on
+    Ls, info = _ragged_factor(gpu, mats, gpu["lib"].POTRF_NB(1), nan_upper=False)
+    assert info[0] == 0 and info[1] == 0 and info[3] == 0
+    # the first non-positive pivot by LAPACK-style elimination on the CPU
+    try:
+        np.linalg.cholesky(mats[2][:1500, :1500])
+    except np.linalg.LinAlgError:  # pragma: no cover
+        pytest.fail("the leading block was meant to be positive definite")
+    lo, hi = 1500, 2300
+    while lo < hi:  # smallest k whose leading minor of order k fails
+        mid = (lo + hi) // 2
+        try:
+            np.linalg.cholesky(mats[2][:mid, :mid]); lo = mid + 1
+        except np.linalg.LinAlgError:
+            hi = mid
+    assert info[2] == lo, (info, lo)
+    for b in (0, 1, 3):
+        ref = np.linalg.cholesky(mats[b])
+        assert np.max(np.abs(Ls[b] - ref)) < 1e-10 * np.max(np.abs(ref)), b
+
+
+def test_potrf_ragged_plan_rejects_odd_orders(gpu):
+    lib, dv = gpu["lib"], gpu["dv"]
+    n, off, ld = np.array([101], dtype=np.int32), np.array([0], dtype=np.int64), np.array([112], dtype=np.int64)
+    plan = np.zeros(int(lib.lib.pta_potrf_ragged_plan_words(1)), dtype=np.int64)
+    need = ctypes.c_int64(0)
+    with pytest.raises(lib.PtaError):
+        lib.call("pta_potrf_ragged_plan", dv.hptr(n), dv.hptr(off), dv.hptr(ld), 1, 0, dv.hptr(plan), ctypes.byref(need))
+
+
 def test_potrf_not_positive_definite_raises(gpu):
     from pta_replicator_amd import red_noise as rn
     dv = gpu["dv"]

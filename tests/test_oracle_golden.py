@@ -300,6 +300,11 @@ def test_td_oracle_covariance_matches_synthesis_statistics():
     U = (epoch_of[:, None] == np.arange(ne)[None, :]).astype(float)
     ref = F @ np.diag(phi) @ F.T + np.diag(sig2) + (U * ec ** 2) @ U.T
     assert np.max(np.abs(Cm - ref)) < 1e-12 * np.max(np.abs(ref))
+    rows = np.array([0, 7, 8, 39, 21])
+    got = po.td_covariance_rows(t, -13.5, 3.0, 10, sig2, epoch_of, ec, rows)          # the row-wise form the full-size config-2 test uses
+    assert np.max(np.abs(got - Cm[rows])) < 1e-14 * np.max(np.abs(Cm))
+    got = po.td_covariance_rows(t, None, None, 10, sig2, epoch_of, ec, rows)
+    assert np.max(np.abs(got - (np.diag(sig2) + (U * ec ** 2) @ U.T)[rows])) < 1e-14 * np.max(np.abs(Cm))
 
 
 def test_red_noise_explicit_modes():
