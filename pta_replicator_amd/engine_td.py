@@ -122,8 +122,8 @@ class TimeDomainMixin:
                 words = int(_lib.lib.pta_potrf_ragged_plan_words(P))
                 plan = np.zeros(words, dtype=np.int64)
                 need = ctypes.c_int64(0)
-                _lib.call("pta_potrf_ragged_plan", dv.hptr(np.asarray(nst, dtype=np.int32)), dv.hptr(np.asarray(pos[:-1], dtype=np.int64)),
-                          dv.hptr(np.asarray(ld, dtype=np.int64)), P, flags, dv.hptr(plan), ctypes.byref(need))
+                h_n, h_off, h_ld = np.ascontiguousarray(nst, dtype=np.int32), np.ascontiguousarray(pos[:-1], dtype=np.int64), np.ascontiguousarray(ld, dtype=np.int64)
+                _lib.call("pta_potrf_ragged_plan", dv.hptr(h_n), dv.hptr(h_off), dv.hptr(h_ld), P, flags, dv.hptr(plan), ctypes.byref(need))
                 self._td_rag_plan, self._td_rag_plan_dev, self._td_rag_need, self._td_rag_key = plan, dv.i64(plan), int(need.value), key
             work = dv.empty((self._td_rag_need,))
             _lib.call("pta_potrf_ragged", dv.ptr(self.d_Ltd), dv.hptr(self._td_rag_plan), dv.ptr(self._td_rag_plan_dev), dv.ptr(info), dv.ptr(work),
