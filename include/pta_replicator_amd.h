@@ -430,7 +430,9 @@ typedef struct {
   const double *z;            /* ABI 3, rows_per_real == 1 only: NULL = every deviate is generated in registers (default); else the deviates
                                  are READ: z[m * ld_z + blk_zoff[b] + j] = deviate j of row m for factor block b - what pta_rng_fill_normal
                                  (interleave = 1) writes for stream (stream_kind, b).  Same numbers either way, bit-identical output.
-                                 Every row needs 16 finite doubles behind its last block (ld_z >= blk_zoff[last] + blk_n[last] + 16) */
+                                 Block b's deviates are whole pairs (blk_n[b] rounded up to even, at least 4 doubles) inside the row:
+                                 ld_z >= blk_zoff[b] + max(4, blk_n[b] + (blk_n[b] & 1)); nothing behind them is read (ABI 6: the
+                                 "16 finite doubles behind the last block" of ABI 5 is gone - the kernel clamps) */
   int64_t ld_z;
   const int32_t *blk_zoff;    /* [n_blocks] first column of block b's deviates inside a row of z (even: pta_rng_fill_normal writes pairs) */
 } pta_td_plan;
@@ -454,7 +456,11 @@ int pta_tm_project(const double *Qt, const double *Mt, int64_t ld, int m, const 
  * concatenation).  `comm` is the caller's ncclComm_t (RCCL); `local` this rank's shard [b_r - a_r, n_cols], `out` (on `dst` only)
  * the [total_rows, n_cols] result.  Asynchronous on `stream`.  world == 1: a device-to-device copy, no communicator needed.  RCCL is
  * bound at run time from the copy already loaded into the process (PyTorch's), so the library has no link-time dependency on it.
- * The reference has no counterpart (single process).                                                              */
+ * The reference has no counterpart (single process).
+ * Restriction (world > 1): rows must be contiguous on both sides - ld_local == n_cols and, on `dst`, ld_out == n_cols (a send is
+ * matched by ONE receive of the same count, so a wider destination would need row-wise sends too); to fill a window of a wider ensemble
+ * tensor, gather into a [total_rows, n_cols] tensor and copy.  world == 1 accepts any leading dimensions.  Thread-safe (the RCCL
+ * binding is resolved once).                                                                                                    */
 int pta_gather_rank0(void *comm, int rank, int world, int dst, const double *local, int64_t total_rows, int64_t n_cols,
                      int64_t ld_local, double *out, int64_t ld_out, void *stream);
 

@@ -2,6 +2,9 @@
 // RCCL is bound at RUN time (dlopen of the copy already loaded into the process - PyTorch's librccl.so - else the system one): the
 // library itself carries no link-time dependency on it, so single-GPU users never load a communication library.
 #include <dlfcn.h>
+#include <link.h>
+#include <string.h>
+#include <mutex>
 #include "pta_common.h"
 
 namespace {
@@ -9,35 +12,47 @@ typedef int (*fn_sendrecv)(void *, size_t, int, int, void *, hipStream_t);  // n
 typedef int (*fn_group)(void);
 typedef const char *(*fn_errstr)(int);
 struct rccl_api {
-  bool tried = false, ok = false;
+  bool ok = false;
   fn_sendrecv send = nullptr, recv = nullptr;
   fn_group gstart = nullptr, gend = nullptr;
   fn_errstr errstr = nullptr;
 };
 rccl_api g_rccl;
+std::once_flag g_rccl_once;
 
-int rccl_load() {
-  rccl_api &r = g_rccl;
-  if (r.tried) return r.ok ? PTA_OK : PTA_E_ARG;
-  r.tried = true;
-  void *h = nullptr;
-  for (const char *name : {"librccl.so", "librccl.so.1"}) {
-    h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);  // the copy the process already uses (torch.distributed's), if any
-    if (h) break;
+// the RCCL copy the process ALREADY uses (torch.distributed's, or the one a ctypes integrator loaded by full path), whatever its SONAME:
+// the loaded-object list is searched for "librccl" and that very file is re-opened (looking it up by the two usual names
+// could miss it and bind a second copy, whose ncclSend would then be handed the first copy's communicator)
+int rccl_find_loaded(struct dl_phdr_info *info, size_t, void *data) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+    snprintf((char *)data, 1024, "%s", info->dlpi_name);
+    return 1;
   }
+  return 0;
+}
+
+void rccl_load_once() {
+  rccl_api &r = g_rccl;
+  char path[1024] = {0};
+  void *h = nullptr;
+  if (dl_iterate_phdr(rccl_find_loaded, path) && path[0]) h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
   if (!h)
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
       h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (h) break;
     }
-  if (!h) return PTA_E_ARG;
+  if (!h) return;
   r.send = (fn_sendrecv)dlsym(h, "ncclSend");
   r.recv = (fn_sendrecv)dlsym(h, "ncclRecv");
   r.gstart = (fn_group)dlsym(h, "ncclGroupStart");
   r.gend = (fn_group)dlsym(h, "ncclGroupEnd");
   r.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
   r.ok = r.send && r.recv && r.gstart && r.gend;
-  return r.ok ? PTA_OK : PTA_E_ARG;
+}
+
+int rccl_load() {
+  std::call_once(g_rccl_once, rccl_load_once);
+  return g_rccl.ok ? PTA_OK : PTA_E_ARG;
 }
 }  // namespace
 
@@ -79,16 +94,22 @@ extern "C" int pta_gather_rank0(void *comm, int rank, int world, int dst, const 
   // point-to-point: `dst` posts one receive per peer STRAIGHT into that peer's rows of `out` (no staging, no concatenation - the
   // destination holds the ensemble once); one group = one fused launch
   PTA_NCCL(g_rccl.gstart());
+  int e = 0;  // first RCCL error inside the group; the group is CLOSED on every path (an open group would swallow the caller's next calls)
   if (rank == dst) {
-    for (int r = 0; r < world; ++r) {
+    for (int r = 0; r < world && e == 0; ++r) {
       if (r == dst) continue;
       int64_t ra, rb;
       pta_shard(total_rows, r, world, &ra, &rb);
-      if (rb > ra) PTA_NCCL(g_rccl.recv(out + ra * ld_out, (size_t)((rb - ra) * n_cols), 8 /* ncclFloat64 */, r, comm, s));
+      if (rb > ra) e = g_rccl.recv(out + ra * ld_out, (size_t)((rb - ra) * n_cols), 8 /* ncclFloat64 */, r, comm, s);
     }
   } else if (b > a) {
-    PTA_NCCL(g_rccl.send(const_cast<double *>(local), (size_t)((b - a) * n_cols), 8, dst, comm, s));
+    e = g_rccl.send(const_cast<double *>(local), (size_t)((b - a) * n_cols), 8, dst, comm, s);
   }
-  PTA_NCCL(g_rccl.gend());
+  const int e_end = g_rccl.gend();
+  if (e == 0) e = e_end;
+  if (e != 0) {
+    pta_set_error("pta_gather_rank0: RCCL send / recv failed: %s", g_rccl.errstr ? g_rccl.errstr(e) : "rccl error");
+    return PTA_E_HIP;
+  }
   return PTA_OK;
 }

@@ -251,7 +251,6 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, SINGLE ? 3 : 4) void k_engine_synt
   // per two TOAs; a tile cut short by the end of the pulsar (clamped lanes) evaluates the pair of every TOA on its own
   const bool wn_share = wn_single && count == PTA_ENGINE_TILE;  // workgroup-uniform
   double zs[4] = {0.0, 0.0, 0.0, 0.0};
-  uint32_t zs_pid = 0xFFFFFFFFu;
   // Loads and stores share the in-order vmcnt on gfx950: waiting for a load also waits for every store issued before it.  The four
   // stores of iteration j are therefore issued one iteration late, BEHIND the operand loads of iteration j + 1 - they then drain
   // under that iteration's Box-Muller chains instead of in front of its first use of a loaded value.
@@ -299,8 +298,10 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, SINGLE ? 3 : 4) void k_engine_synt
       // step evaluates its own pair
       const uint32_t pid = pair & ~16u;
       const bool br = (pair & 16u) != 0;
-      bool fresh = (j & 1) == 0;
-      if ((j & 1) && !wn_share) fresh = __any((int)(pid != zs_pid));
+      // (the odd step of a short tile used to reuse zs whenever no lane's pair id differed from the even step's - true also
+      // when both steps are clamped to the pulsar's LAST TOA, whose own branch was then replaced by its partner's.  A short tile now
+      // evaluates every step: workgroup-uniform, the last tile of a pulsar only.)
+      const bool fresh = (j & 1) == 0 || !wn_share;
       if (fresh) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -309,7 +310,6 @@ __global__ __launch_bounds__(PTA_ENGINE_TILE, SINGLE ? 3 : 4) void k_engine_synt
           v[g] = v[g] + wa * (br ? z1 : z0);
           zs[g] = br ? z0 : z1;   // the other branch, for the partner TOA
         }
-        zs_pid = pid;
       } else {
 #pragma unroll
         for (int g = 0; g < 4; ++g) v[g] = v[g] + wa * zs[g];

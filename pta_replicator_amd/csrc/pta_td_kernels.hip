@@ -401,8 +401,9 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   typedef double pta_f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
   const double *__restrict__ zrow = nullptr;
   pta_f64x2_a8 zn0 = {0.0, 0.0}, zn1 = {0.0, 0.0};
-  auto zfetch = [&](int k0) {  // a slab may reach up to 15 columns past the factor's order: the next block's deviates or the row's padding
-    const int kk = k0 + 4 * q;  // (finite either way, and multiplied by masked - zero - entries of L)
+  const int zlim = max(0, ((n + 1) & ~1) - 4);  // last k at which this lane's two pairs lie inside the block's own (whole) pairs
+  auto zfetch = [&](int k0) {  // a slab may reach up to 15 columns past the factor's order: those k are clamped back into the block's
+    const int kk = min(k0 + 4 * q, zlim);  // own deviates (finite; they multiply masked - zero - entries of L), so nothing behind the block is read
     zn0 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk);
     zn1 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk + 2);
   };

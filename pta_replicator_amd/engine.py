@@ -426,6 +426,13 @@ class ReplicaEngine(TimeDomainMixin):
         pl.wn_c = self.d_wn_c.data_ptr()
         return pl
 
+    def _require_reference_draws(self, what):
+        """the replay entry points describe the reference's draws (two deviates per TOA, white_noise.py:105-109): in wn_mode "single"
+        generate() draws something else, so they refuse instead of silently answering for another mode."""
+        if self.wn_mode != "reference" and self._wn is not None:
+            raise ValueError(f"{what}() describes the reference-order draws; wn_mode={self.wn_mode!r} realisations are not replayable "
+                             "(use dump_draws_wn_single / generate_per_signal, or set wn_mode = 'reference')")
+
     def dump_draws_wn_single(self, r):
         """the ONE deviate per TOA realisation r uses in wn_mode "single": TOA idx of pulsar a takes branch (idx >> 4) & 1 of pair
         idx & ~16 of stream (WN, a) - one array per pulsar."""
@@ -451,14 +458,15 @@ class ReplicaEngine(TimeDomainMixin):
             raise ValueError(f"generate_per_signal: at most {self.max_batch()} realisations per call (one workspace batch)")
         total = self.generate(R, r0=r0)                      # also fills the workspace (coefficients, mixed GWB grid series)
         s = dv.stream_ptr()
-        keep = (self.plan.rn_k, self.plan.gw_npts, self.plan.wn_a, self.plan.wn_b, self.plan.ecorr_toa, self.plan.epoch_of, self.plan.det)
+        base = self._plan_for_mode()                         # wn_mode "single": the white-noise term is the one-deviate form, as in generate()
+        keep = (self.plan.rn_k, self.plan.gw_npts, base.wn_a, base.wn_b, self.plan.ecorr_toa, self.plan.epoch_of, self.plan.det, base.wn_c)
         out = {"total": total}
 
         def one(name, **on):
             pl = _lib.EnginePlan.from_buffer_copy(self.plan)   # a private copy: the shared plan is never mutated
-            pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det = (
+            pl.rn_k, pl.gw_npts, pl.wn_a, pl.wn_b, pl.ecorr_toa, pl.epoch_of, pl.det, pl.wn_c = (
                 on.get("rn_k", 0), on.get("gw_npts", 0), on.get("wn_a"), on.get("wn_b"), on.get("ecorr_toa"),
-                on.get("epoch_of"), on.get("det"))
+                on.get("epoch_of"), on.get("det"), on.get("wn_c"))
             buf = dv.empty((R, self.n_toa))
             _lib.call("pta_engine_synth", ctypes.byref(pl), self.seed, r0, R, dv.ptr(buf), buf.stride(0), s)
             out[name] = buf
@@ -466,8 +474,8 @@ class ReplicaEngine(TimeDomainMixin):
             one("rn", rn_k=keep[0])
         if keep[1]:
             one("gwb", gw_npts=keep[1])
-        if keep[2]:
-            one("wn", wn_a=keep[2], wn_b=keep[3])
+        if keep[2] or keep[7]:
+            one("wn", wn_a=keep[2], wn_b=keep[3], wn_c=keep[7])
         if keep[4]:
             one("ecorr", ecorr_toa=keep[4], epoch_of=keep[5])
         if keep[6]:
@@ -514,6 +522,7 @@ class ReplicaEngine(TimeDomainMixin):
     def dump_draws(self, r):
         """The normals realisation r uses in generate(), as NumPy arrays in the reference's shapes:
         {'gwb': w[P,Nf] complex, 'rn': [z[K]], 'wn': [(z1[N_a], z2[N_a])], 'ecorr': [z[E_a]]}."""
+        self._require_reference_draws("dump_draws")
         if not self._prepared:
             self.prepare()
         s = dv.stream_ptr()
@@ -554,6 +563,7 @@ class ReplicaEngine(TimeDomainMixin):
 
         draws_list: one dict per realisation, shaped like dump_draws().  Returns out[R, n_toa] (device), or with
         per_signal=True a dict of such tensors keyed 'rn', 'gwb', 'wn', 'ecorr', 'det', 'total'."""
+        self._require_reference_draws("replay")
         if not self._prepared:
             self.prepare()
         s = dv.stream_ptr()

@@ -57,13 +57,17 @@ def flag_codes(toas, flagid):
     """(labels, codes): ``labels[codes[i]]`` is the value of flag ``flagid`` of TOA i - what the reference rebuilds on every call
     as ``np.array([f[flagid] for f in toas.table['flags'].data])`` (white_noise.py:98-99,161; half of a call's time at 5000 TOAs).
     Built once per (TOA object, flagid) and cached on the object; flags are injection-invariant (adjust_TOAs does not touch them).
-    The cache is keyed by the TOA count and spot-checked against the live flags (first / middle / last TOA)."""
+    The cache is keyed by the TOA count and spot-checked against the live flags at 16 positions (ends, middle, a fixed pseudo-random
+    set).  INVARIANT the caller owns: flags edited in place between add_* calls are not seen - the reference re-reads them on every
+    call - so after such an edit call ``clear_caches(psr)``; the errors column has no such caveat (content-checked)."""
     data = toas.table["flags"].data
     n = len(data)
     cache = getattr(toas, "_pta_flag_codes", None)
     hit = cache.get(flagid) if isinstance(cache, dict) else None
-    if hit is not None and hit[0] == n and all(str(hit[1][hit[2][i]]) == str(data[i][flagid]) for i in {0, n // 2, n - 1}):
-        return hit[1], hit[2]
+    if hit is not None and hit[0] == n and n > 0:
+        probe = {0, n // 2, n - 1} | {int(k) for k in (np.arange(1, 14) * 2654435761 % n)}
+        if all(str(hit[1][hit[2][i]]) == str(data[i][flagid]) for i in probe):
+            return hit[1], hit[2]
     col = np.array([f[flagid] for f in data])
     labels, codes = np.unique(col, return_inverse=True)
     codes = codes.astype(np.int32)
@@ -75,6 +79,16 @@ def flag_codes(toas, flagid):
     except AttributeError:      # an object that refuses new attributes: no cache, same result
         pass
     return labels, codes
+
+
+def clear_caches(obj):
+    """forget the per-TOA-object caches (flag index, errors in seconds) of a pulsar or TOA container - after editing flags in place."""
+    toas = getattr(obj, "toas", obj)
+    for name in ("_pta_flag_codes", "_pta_errors_s"):
+        try:
+            toas.__dict__.pop(name, None)
+        except AttributeError:
+            pass
 
 
 def _per_flag_vector(labels, codes, flags, values):
@@ -89,15 +103,16 @@ def _per_flag_vector(labels, codes, flags, values):
 def errors_seconds(toas):
     """TOA uncertainties in seconds as float64 (white_noise.py:105: ``get_errors().to('s')``), converted once per TOA object - the
     errors are injection-invariant - and cached on it (keyed by the TOA count)."""
-    n = toas.ntoas
+    src = getattr(toas, "errors_us", None)      # array-backed TOAs: the source column itself (no unit conversion needed to validate)
     hit = getattr(toas, "_pta_errors_s", None)
-    if hit is not None and len(hit) == n:
-        return hit
+    if src is not None and hit is not None and hit[0] is src and len(hit[2]) == len(src) and np.array_equal(hit[1], src):
+        return hit[2]                            # same column object, same content (ADVICE r3: a rescaled error column must not be served stale)
     sig = np.asarray(toas.get_errors().to("s").value, dtype=np.float64)
-    try:
-        toas._pta_errors_s = sig
-    except AttributeError:
-        pass
+    if src is not None:
+        try:
+            toas._pta_errors_s = (src, np.array(src, copy=True), sig)
+        except AttributeError:
+            pass
     return sig
 
 
@@ -156,11 +171,32 @@ def _legacy_normals(seeds, counts):
 
 
 def _broadcast(val, P, what):
-    if isinstance(val, (list, tuple)) and len(val) == P:
+    if isinstance(val, (list, tuple, np.ndarray)) and np.ndim(val) >= 1 and len(val) == P:
         return list(val)
-    if val is None or np.isscalar(val):
+    if val is None or np.isscalar(val) or np.ndim(val) == 0:
         return [val] * P
     raise ValueError(f"{what}: expected a scalar or one entry per pulsar ({P})")
+
+
+def _seed_list(seed, P):
+    """None, or one seed per pulsar (the list forms re-seed per pulsar exactly as the loop of single calls would)."""
+    if seed is None:
+        return None
+    if np.ndim(seed) == 0:
+        raise ValueError("seed must be None or one seed per pulsar (a sequence), not a single value: the loop of single calls re-seeds per pulsar")
+    seeds = list(seed)
+    if len(seeds) != P:
+        raise ValueError("seed must be None or one seed per pulsar")
+    return seeds
+
+
+def _pow10(l10):
+    """10 ** log10_value exactly as the single-pulsar path computes it: a Python / NumPy SCALAR goes through libm's pow (``10 ** float``),
+    only a genuine vector through NumPy's ufunc loop - whose SIMD build may differ from libm by an ulp, which would break the
+    bit-identity of a list call with the loop of single calls."""
+    if np.ndim(l10) == 0:
+        return 10 ** (l10.item() if isinstance(l10, np.generic) or isinstance(l10, np.ndarray) else l10)
+    return 10 ** np.asarray(l10, dtype=float)
 
 
 def _record_wn(psr, efac, log10_equad, flags, equad_str, dt):
@@ -211,14 +247,11 @@ def _add_measurement_noise_list(psrs, efac, log10_equad, flagid, flags, seed, tn
     if flags is not None and (len(flags) != P or not all(f is None or isinstance(f, (list, tuple, np.ndarray)) for f in flags)):
         raise ValueError("flags must be a per-pulsar list of flag lists")
     flagl = flags if flags is not None else [None] * P
-    seeds = None if seed is None else list(seed)
-    if seeds is not None and len(seeds) != P:
-        raise ValueError("seed must be None or one seed per pulsar")
+    seeds = _seed_list(seed, P)
     counts = [p.toas.ntoas for p in psrs]
     vecs = []
     for a, p in enumerate(psrs):
-        equad = 10 ** np.asarray(l10s[a], dtype=float) if l10s[a] is not None else 0.0
-        equad = float(equad) if np.ndim(equad) == 0 else equad
+        equad = _pow10(l10s[a]) if l10s[a] is not None else 0.0
         vecs.append(_wn_vectors(p, efacs[a], equad, flagid, flagl[a]))
     z = _legacy_normals(seeds, [[n, n] for n in counts])
     sigma = np.concatenate([errors_seconds(p.toas) for p in psrs])
@@ -288,15 +321,12 @@ def _add_jitter_list(psrs, log10_ecorr, flagid, flags, coarsegrain, seed):
     if flags is not None and len(flags) != P:
         raise ValueError("flags must be a per-pulsar list of flag lists")
     flagl = flags if flags is not None else [None] * P
-    seeds = None if seed is None else list(seed)
-    if seeds is not None and len(seeds) != P:
-        raise ValueError("seed must be None or one seed per pulsar")
+    seeds = _seed_list(seed, P)
     eps, vecs, nes = [], [], []
     for a, p in enumerate(psrs):
         times = np.asarray(p.toas.get_mjds().value, dtype=np.float64)
         epoch_of, first = epoch_map(times, coarsegrain)
-        ecorr = 10 ** np.asarray(l10s[a], dtype=float)
-        ecorr = float(ecorr) if np.ndim(ecorr) == 0 else ecorr
+        ecorr = _pow10(l10s[a])
         vecs.append(_ecorr_vector(p, ecorr, flagid, flagl[a], first))
         eps.append(epoch_of)
         nes.append(len(first))

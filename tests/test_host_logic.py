@@ -187,6 +187,51 @@ def test_ecliptic_branch_restatement_is_sane():
     assert abs(np.degrees(ra) / 15 - (18 + 55 / 60 + 13.7 / 3600)) < 2e-3 and abs(np.degrees(dec) - (9 + 39 / 60 + 13 / 3600)) < 5e-3
 
 
+def test_ecliptic_branch_against_an_independent_evaluation_and_warns_once():
+    """the libastro restatement (obliquity of the coordinate's epoch, two-leg IAU 1976 precession in rounded degrees) against an
+    independent rotation-matrix evaluation with the arcsecond-valued IAU constants: agreement below a milliarcsecond bounds formula
+    errors (the 7-decimal degree coefficients and the 84381.44796" obliquity differ from the IAU values at the 1e-10 rad level - the
+    reason the ELONG / ELAT branch cannot be claimed at 1e-10 without a pyephem fixture); ra_dec() warns once per process."""
+    import warnings
+    from pta_replicator_amd import _position as pos
+    asec = np.pi / 180 / 3600
+
+    def rot(axis, a):
+        c, s = np.cos(a), np.sin(a)
+        return {1: np.array([[1, 0, 0], [0, c, s], [0, -s, c]]), 2: np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]]),
+                3: np.array([[c, s, 0], [-s, c, 0], [0, 0, 1]])}[axis]
+
+    def independent(lon, lat, b1950):
+        lam, bet = np.radians(lon), np.radians(lat)
+        v = np.array([np.cos(bet) * np.cos(lam), np.cos(bet) * np.sin(lam), np.sin(bet)])
+        v = rot(1, -84381.448 * asec) @ v                       # ecliptic -> equatorial, J2000
+        if b1950:
+            T = -0.5
+            zeta, z, th = [(a * T + b * T ** 2 + c * T ** 3) * asec for a, b, c in
+                           ((2306.2181, 0.30188, 0.017998), (2306.2181, 1.09468, 0.018203), (2004.3109, -0.42665, -0.041833))]
+            v = rot(3, -z) @ rot(2, th) @ rot(3, -zeta) @ v      # IAU 1976 precession matrix J2000 -> date
+        return np.arctan2(v[1], v[0]) % (2 * np.pi), np.arcsin(v[2])
+
+    rng = np.random.default_rng(3)
+    for lon, lat in [(286.863485782621126, 32.321482985635249), (284.2208542340, -15.1555138035)] + [(rng.uniform(0, 360), rng.uniform(-85, 85)) for _ in range(40)]:
+        for name in ("B1855+09", "J1909-3744"):
+            ra, dec = pos.ecliptic_to_equatorial(lon, lat, name)
+            ra0, dec0 = independent(lon, lat, "B" in name)
+            d = np.hypot((((ra - ra0) + np.pi) % (2 * np.pi) - np.pi) * np.cos(dec0), dec - dec0)
+            assert d < 1e-3 * asec, (lon, lat, name, d / asec)
+
+    class P:
+        name = "B1855+09"
+        loc = {"ELONG": 286.863485782621126, "ELAT": 32.321482985635249}
+    if pos._ephem is None:
+        pos._warned = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pos.ra_dec(P)
+            pos.ra_dec(P)
+        assert len(w) == 1 and "1e-10" in str(w[0].message)
+
+
 def test_population_split_matches_the_reference_bookkeeping():
     """deterministic.py:617-676 on the host: strain of every binary, loudest-per-bin selection (incl. an exact tie and a bin
     with fewer members than outlier_per_bin), free spectrum of the rest - against the reference run on the holodeck stub."""
