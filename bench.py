@@ -109,14 +109,14 @@ def src_sha(*files):
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
 SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 CZT_SRC = ("pta_czt_kernels.hip", "pta_fft.h", "pta_rng.h", "pta_rng_tables.h")
 
 
 def pmc_entry(key, srcs, **shape):
-    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r3.sh -> profiles/r03_pmc.json),
+    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r4.sh -> profiles/r04_pmc.json),
     or (None, reason) when the file is missing, was taken at another launch shape, or the kernel sources changed since."""
     try:
         with open(PMC_FILE) as fh:
@@ -295,6 +295,28 @@ def td_mode_numbers(eng, R):
         del work
         tp = min(ts)
         res.update({"potrf_workspace_GB": 8.0 * need / 1e9, "potrf_without_workspace_ms": min(ts_free) * 1e3})
+        # the same batch through the END-ALIGNED ragged schedule (pta_potrf_ragged; a uniform batch is its special case front = const)
+        try:
+            tr = []
+            for _ in range(3):
+                wall(assemble)
+                tr.append(wall(lambda: eng.td_factorise(mode="ragged")))
+            res["potrf_ragged_schedule_ms"] = min(tr) * 1e3
+            res["potrf_ragged_schedule_TFLOPs"] = flop_chol / min(tr) / 1e12
+            wall(assemble)
+            eng.td_factorise(mode="uniform")
+        except Exception as e:  # pragma: no cover
+            res["potrf_ragged_schedule_error"] = str(e)[:200]
+
+        def factor_loop():
+            assemble()
+            _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD, dv.ptr(work2), need, s)
+        work2 = dv.empty((need,))
+        ck = engine_clock_during(factor_loop, 0.6)
+        del work2
+        if ck:
+            res["potrf_engine_clock_GHz"] = ck["GHz"]
+        eng.prepare_td()
         res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_GBps_lower_triangle": 8.0 * sum(n * (n + 64) / 2 for n in counts) / ta / 1e9,
                     "potrf_ms": tp * 1e3, "potrf_TFLOPs": flop_chol / tp / 1e12, "potrf_frac_of_fp64_mfma_peak": flop_chol / tp / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "positive_definite": int(info.abs().sum().item()) == 0})
@@ -308,6 +330,12 @@ def td_mode_numbers(eng, R):
     eng.generate_td(R, out=out)
     t = wall(lambda: eng.generate_td(R, out=out), 2)
     flop = float(sum(n * n for n in counts))       # useful flops per realisation of L.z (triangular): sum N_a^2
+    ck = engine_clock_during(lambda: eng.generate_td(R, out=out), 0.5)
+    if ck:
+        res["trmm_engine_clock_GHz"] = ck["GHz"]
+        res["trmm_frac_at_measured_clock"] = flop * R / t / 1e12 / (FP64_MFMA_PEAK_TFLOPS * ck["GHz"] / 2.4)
+        if res.get("potrf_engine_clock_GHz") and res.get("potrf_TFLOPs"):
+            res["potrf_frac_at_measured_clock"] = res["potrf_TFLOPs"] / (FP64_MFMA_PEAK_TFLOPS * res["potrf_engine_clock_GHz"] / 2.4)
     res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
                 "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "td_draws": "memory (deviates written once per batch, read by the product)",
@@ -323,7 +351,7 @@ def td_mode_numbers(eng, R):
         if e:
             if big:
                 res[name + "_all_dispatches"] = e["mfma_busy_pct"]
-                res[name.replace("mfma_busy_pct", "engine_clock_GHz")] = big["engine_clock_GHz"]
+                res[name.replace("mfma_busy_pct", "gui_active_cycles_per_xcd_per_ns")] = big.get("gui_active_cycles_per_xcd_per_ns")   # NOT a clock (launch gaps)
             res[name + "_source"] = e.get("source")
             if key == "k_td_cov128" and e.get("hbm_write_GBps"):   # counter bytes (WRITE_SIZE) over the rocprofv3 launch time
                 res["cov_assemble_GBps_from_WRITE_SIZE"] = e["hbm_write_GBps"]
@@ -376,6 +404,42 @@ def _wall(fn, reps=1):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
+
+
+def engine_clock_during(fn, seconds=0.5):
+    """median engine clock [GHz] while `fn` loops on the current stream: pta_clock_probe (one wave on a side stream sampling
+    s_memrealtime / s_memtime every 100 us; the slope between samples is the clock).  Returns {"GHz", "p05", "p95", "idle_GHz"}."""
+    import torch
+    from pta_replicator_amd import _lib
+    ns = int((seconds + 0.25) * 1e4) + 16
+    buf = torch.zeros((ns, 2), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    fn()
+    torch.cuda.synchronize()
+    _lib.call("pta_clock_probe", buf.data_ptr(), ns, int((seconds + 0.2) * 1e6), 100, side.cuda_stream)
+    time.sleep(0.06)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.current_stream().synchronize()
+    torch.cuda.synchronize()
+    smp = buf.cpu().numpy()
+    smp = smp[smp[:, 0] > 0]
+    if len(smp) < 8:
+        return None
+    rt, sc = smp[:, 0].astype(np.float64), smp[:, 1].astype(np.float64)
+    ghz = np.diff(sc) / (np.diff(rt) * 10.0)
+    tt = (rt[1:] - rt[0]) / 1e8
+    busy = (tt > 0.06 + 0.25 * seconds) & (tt < 0.06 + 0.9 * seconds)
+    idle = tt < 0.04
+    if busy.sum() < 8:
+        return None
+    return {"GHz": float(np.median(ghz[busy])), "p05": float(np.percentile(ghz[busy], 5)), "p95": float(np.percentile(ghz[busy], 95)),
+            "idle_GHz": float(np.median(ghz[idle])) if idle.any() else None,
+            "method": "pta_clock_probe: s_memtime / s_memrealtime slope, 100 us samples on a side stream beside the loop"}
 
 
 def td_ragged_numbers(P=42, R=256, compare_per_matrix=True):
@@ -654,6 +718,18 @@ def main():
     timed("pta_gwb_mix", lambda: _lib.call("pta_gwb_mix", dv.ptr(eng.d_M), P, dv.ptr(ws["G0"]), R, npts, npts, dv.ptr(ws["G"]), 0, s))
     timed("pta_engine_synth", lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s))
 
+    # ---- engine clock while the hot kernels run: in-kernel probe on a side stream, N = 1 only ----
+    clocks = {}
+    if world == 1 and not args.no_extras:
+        try:
+            clocks["pta_engine_synth"] = engine_clock_during(lambda: _lib.call("pta_engine_synth", ctypes.byref(eng.plan), eng.seed, 0, R, dv.ptr(out), out.stride(0), s), 0.4)
+            if eng.use_czt:
+                clocks["pta_gwb_czt"] = engine_clock_during(lambda: _lib.call("pta_gwb_czt", eng.seed, 0, None, 0, R, P, Nf, npts, 10, *[dv.ptr(x) for x in eng.d_czt],
+                                                                              dv.ptr(ws["G0"]), npts, 0, 0, s), 0.4)
+            clocks["step"] = engine_clock_during(lambda: eng.generate(R, r0=base, out=out), 0.4)
+        except Exception as e:  # pragma: no cover
+            clocks["error"] = str(e)[:200]
+
     def gather_phase(line):
         """N > 1: the north_star's gather of the residual arrays to rank 0, pipelined with generation.  Runs LAST and under a
         60 s watchdog: the RCCL path cannot be exercised on the 1-GPU development box (two ranks on one device over gloo move
@@ -721,6 +797,14 @@ def main():
                                    "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k], "valu_busy_pmc": e.get("valu_busy")}
         else:
             d["traffic_note"] = why
+        ck = clocks.get(k)
+        if ck:   # the clock the chip holds under this kernel (DVFS by instruction mix: 2.40 GHz idle / under MFMA, ~2.3 under fp64 VALU + Philox)
+            d["engine_clock_GHz"] = ck["GHz"]
+            if "valu_issue" in d:
+                im = d["valu_issue"]["insts_valu"] * 4.0 / (256 * 4) / (ck["GHz"] * 1e9) * 1e3
+                d["valu_issue"]["issue_ms_at_measured_clock"] = im
+                d["valu_issue"]["frac_of_launch_at_measured_clock"] = im / kern[k]
+            d["frac_at_measured_clock"] = d["frac"]   # an HBM roof does not move with the engine clock; the issue-bound view is valu_issue
         return d
 
     def flop_roof(k):
@@ -750,6 +834,10 @@ def main():
                                        "issue_ms_at_2.4GHz": issue_ms, "frac_of_launch": issue_ms / kern[k], "valu_busy_pmc": e.get("valu_busy")}
             else:
                 d["traffic_note"] = why
+        ck = clocks.get(k)
+        if ck:
+            d["engine_clock_GHz"] = ck["GHz"]
+            d["frac_at_measured_clock"] = ach / (FP64_MFMA_PEAK_TFLOPS * ck["GHz"] / 2.4)
         return d
 
     if kern["pta_engine_synth"] >= kern[gwb_kernel]:
@@ -783,6 +871,27 @@ def main():
             td = td_mode_numbers(eng, 1024)   # the whole array: 68 x 5000^2 fp64 = 13.6 GB of factors
         except Exception as e:  # pragma: no cover
             td = {"error": str(e)[:300]}
+        if not args.no_extras:
+            eng.d_Ltd = None                  # release the 13.6 GB before the 48 GB of the ragged array
+            eng._td_prepared = False
+            torch.cuda.empty_cache()
+            try:   # TD mode on an ng15-like RAGGED array: 42 pulsars, TOA counts log-uniform 500 ... 35 000, sum = 340 915 (VERDICT r3 #1b)
+                td["ragged"] = td_ragged_numbers()
+                if td.get("potrf_TFLOPs"):
+                    td["ragged"]["potrf_TFLOPs_over_uniform_68x5000"] = td["ragged"]["potrf_TFLOPs"] / td["potrf_TFLOPs"]
+            except Exception as e:  # pragma: no cover
+                td["ragged"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
+
+    # ---- four cells of the (N_psr, N_toa) grid the north_star asks for (the full grid: scripts/gpu_grid_sweep.py -> profiles/r04_grid.json) ----
+    grid = None
+    if world == 1 and not args.no_extras:
+        grid = []
+        for gp, gn, gtd in ((3, 122, True), (16, 1000, True), (3, 10000, True), (200, 10000, False)):
+            try:
+                grid.append(grid_cell(gp, gn, td=gtd))
+            except Exception as e:  # pragma: no cover
+                grid.append({"n_psr": gp, "n_toa": gn, "error": str(e)[:200]})
 
     # ---- step level (VERDICT r2 #1b): the whole step against the algorithmic flop and deviate counts of SURVEY.md §8d ----
     n_epochs = int(sum(len(v) for v in eng.ecorrvec)) if getattr(eng, "ecorrvec", None) else 0
@@ -793,6 +902,8 @@ def main():
                   "achieved_TFLOPs": flops_alg * R / step_s / 1e12, "frac_of_fp64_peak": flops_alg * R / step_s / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                   "normals_T_per_s": deviates * R / step_s / 1e12,
                   "frac_of_rng_microbench": (deviates * R / step_s / 1e12 / micro["normals_T_per_s"]) if micro.get("normals_T_per_s") else None,
+                  "engine_clock_GHz": (clocks.get("step") or {}).get("GHz"),
+                  "frac_of_fp64_peak_at_measured_clock": (flops_alg * R / step_s / 1e12 / (FP64_MFMA_PEAK_TFLOPS * clocks["step"]["GHz"] / 2.4)) if clocks.get("step") else None,
                   "sum_kernels_ms": sum(kern[k] for k in ("pta_engine_rn_coef", gwb_kernel, "pta_gwb_mix", "pta_engine_synth")),
                   "note": "flops = 4 P^2 Nf + 5 n log2 n P + 2 K sum N_a + 10 sum N_a; deviates = 2 P Nf + P K + 2 sum N_a + sum E_a (SURVEY.md §8d)"}
 
@@ -821,6 +932,11 @@ def main():
                 td["config5_committed_measurement"] = {"error": str(exc)}
     if cfg4 is not None:
         line["config4_shape"] = cfg4
+    if grid is not None:
+        line["grid"] = grid
+        line["grid_full"] = "profiles/r04_grid.json / r04_grid.txt (scripts/gpu_grid_sweep.py: P in {3, 16, 68, 200} x N in {122, 1000, 5000, 10000, 35000})"
+    if clocks:
+        line["engine_clocks"] = clocks
     if world == 1 and not args.no_extras:
         try:
             api = api_mode_timing(psrs, noise)

@@ -482,6 +482,12 @@ int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, in
  * and the FMA loop on alternating waves of the same SIMDs (sum of both rates: do they share the fp64 ALUs?).  kinds 0 / 1 / 4 / 5: `bytes` in 1..32 = 256-thread blocks per CU.       */
 int pta_microbench(int kind, int64_t bytes, int iters, int option, double *result_host);   /* option of kind 4: 0 = default fp64 transform, 1 = rng_fast, 2 = the polynomial fp64 transform (A/B) */
 
+/* Engine-clock probe (ABI 6): one wave on `stream` samples (s_memrealtime [100 MHz ticks], s_memtime [shader cycles]) into
+ * samples[2 i], samples[2 i + 1] every `period_us` for `us` microseconds (at most max_samples pairs; unused slots zeroed).  Launch it
+ * on a side stream, run the kernels of interest on another, and the slope cycles / (10 ns) between samples is the engine clock in GHz
+ * while they ran (bench.py: roofline.engine_clock_GHz; scripts/gpu_r4_clocks.py).  Asynchronous.                                   */
+int pta_clock_probe(uint64_t *samples, int max_samples, int us, int period_us, void *stream);
+
 /* self-test of the fp64 MFMA lane layout used by the GEMM kernels: returns 0 when a 16x16x4
  * product with asymmetric operands matches the scalar result on the device.                */
 int pta_selftest_mfma_f64(double *max_err_host);

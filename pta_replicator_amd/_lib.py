@@ -112,6 +112,7 @@ _SIGNATURES = {
     "pta_dgemm": (c_int, [c_int, c_int, c_int, c_int, c_double, _P, c_int64, c_int64, _P, c_int64, c_double, _P, c_int64,
                           c_int, c_int, c_int64, c_int64, c_int64, c_int, _P]),
     "pta_microbench": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_double)]),
+    "pta_clock_probe": (c_int, [_P, c_int, c_int, c_int, _P]),
     "pta_selftest_mfma_f64": (c_int, [POINTER(c_double)]),
 }
 

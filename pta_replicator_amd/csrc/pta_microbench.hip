@@ -203,3 +203,36 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
   *result_host = work / (ms * 1e-3) / 1e12;  // T(flop|byte|normal)/s
   return PTA_OK;
 }
+
+// ---- engine-clock probe ------------------------------------------------------------------------------------------
+// ONE wave spins for `us` microseconds of constant-rate time and writes a pair (s_memrealtime, s_memtime) every `period_us`: s_memtime
+// ticks once per shader cycle, s_memrealtime at the constant 100 MHz reference (MI355X_MICROARCH.md), so the slope between two samples
+// IS the engine clock over that interval - measured on the chip, beside whatever the caller's other streams run.  (The per-dispatch
+// quotient GRBM_GUI_ACTIVE / duration of round 3 folded launch gaps into the clock: it read 1.8-2.1 GHz for 3-ms dispatches that this
+// probe shows running at 2.28-2.30.)  Asynchronous on `stream`; unused sample slots are zeroed.
+__global__ __launch_bounds__(64) void k_clock_probe(uint64_t *__restrict__ out, int max_samples, int us, int period_us) {
+  if (threadIdx.x != 0) return;
+  const uint64_t t0 = wall_clock64();
+  const uint64_t t_end = t0 + (uint64_t)us * 100u;
+  uint64_t next = t0;
+  int n = 0;
+  while (n < max_samples) {
+    const uint64_t rt = wall_clock64();
+    if (rt >= next) {
+      out[2 * n] = rt;
+      out[2 * n + 1] = clock64();
+      ++n;
+      next += (uint64_t)period_us * 100u;
+    }
+    if (rt >= t_end) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  for (int i = n; i < max_samples; ++i) out[2 * i] = 0, out[2 * i + 1] = 0;
+}
+
+extern "C" int pta_clock_probe(uint64_t *samples, int max_samples, int us, int period_us, void *stream) {
+  PTA_REQUIRE(samples && max_samples >= 2 && us > 0 && period_us > 0, PTA_E_ARG, "pta_clock_probe: bad argument");
+  hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, pta_stream(stream), samples, max_samples, us, period_us);
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}

@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 from bench import CZT_SRC, SYNTH_SRC, TD_SRC, src_sha
 
 out_dir, R, n_toa, n_psr = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+TAG = sys.argv[5] if len(sys.argv) > 5 else "r03"
 
 
 def sums(pass_dir, match, grid=None):
@@ -43,12 +44,12 @@ ms, nt = avg_ms(k)
 if nf and nw:
     e = {"R": R, "n_toa": n_toa, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
          "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*SYNTH_SRC),
-         "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
+         "source": f"profiles/{TAG}_rocprofv3_summary.txt (scripts/gpu_profile_{TAG[:1]}{int(TAG[1:])}.sh)"}
     if na:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE"):
             e["valu_busy"] = a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD) if a.get("SQ_ACTIVE_INST_VALU") else None
-            e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
+            e["gui_active_cycles_per_xcd_per_ns"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None   # NOT the engine clock: launch gaps are in the duration (r04_clocks.txt)
     res[k] = e
 # ---- chirp-z kernel of the GWB stage (default variant, fp64 transform): one workgroup per (realisation, pulsar) row
 k = "k_gwb_czt<true, false, 15>"
@@ -59,12 +60,12 @@ ms, nt = avg_ms(k)
 if nf and nw:
     e = {"rows": R * n_psr, "fetch_kib": f.get("FETCH_SIZE"), "write_kib": w.get("WRITE_SIZE"), "avg_launch_ms_rocprof": ms,
          "dispatches": {"fetch": nf, "write": nw, "sq": na, "trace": nt}, "src_sha": src_sha(*CZT_SRC),
-         "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
+         "source": f"profiles/{TAG}_rocprofv3_summary.txt (scripts/gpu_profile_{TAG[:1]}{int(TAG[1:])}.sh)"}
     if na:
         e["insts_valu"] = a.get("SQ_INSTS_VALU")
         if a.get("GRBM_GUI_ACTIVE") and a.get("SQ_ACTIVE_INST_VALU"):
             e["valu_busy"] = a["SQ_ACTIVE_INST_VALU"] * 4 / (a["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD)
-            e["engine_clock_GHz"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None
+            e["gui_active_cycles_per_xcd_per_ns"] = a["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None   # NOT the engine clock: launch gaps are in the duration (r04_clocks.txt)
     res[k] = e
 # ---- MFMA kernels of TD mode: busy % = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles, time-weighted over the kernel's dispatches; HBM bytes from
 # the FETCH_SIZE / WRITE_SIZE passes (KiB per dispatch; this round those passes run WITH TD mode)
@@ -90,7 +91,7 @@ def large_dispatches(match, min_ms=1.0):
                     busy += float(r["Counter_Value"])
     if not n or not gui:
         return None
-    return {"dispatches": len(n), "min_ms": min_ms, "mfma_busy_pct": 100.0 * busy / (gui * SIMD_PER_XCD), "engine_clock_GHz": gui / 8 / (tot * 1e6)}
+    return {"dispatches": len(n), "min_ms": min_ms, "mfma_busy_pct": 100.0 * busy / (gui * SIMD_PER_XCD), "gui_active_cycles_per_xcd_per_ns": gui / 8 / (tot * 1e6)}
 
 
 for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_td_trmm_rng<false, false>", "k_td_cov128", "k_diag128", "k_trsm_mfma",
@@ -100,10 +101,10 @@ for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_t
     if nm and m.get("GRBM_GUI_ACTIVE"):
         e = {"n_psr": n_psr, "mfma_busy_pct": 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * SIMD_PER_XCD),
              "executed_TFLOPs": m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 64 * 2048 / (ms * 1e-3) / 1e12 if ms else None,
-             "engine_clock_GHz_under_pmc": m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None,
+             "gui_active_cycles_per_xcd_per_ns": m["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6) if ms else None,
              "mfma_busy_cycles_per_dispatch": m.get("SQ_VALU_MFMA_BUSY_CYCLES"), "gui_active_cycles_per_dispatch": m["GRBM_GUI_ACTIVE"],
              "insts_valu_per_dispatch": m.get("SQ_INSTS_VALU"), "avg_launch_ms_rocprof": ms, "dispatches": nm, "src_sha": src_sha(*TD_SRC),
-             "source": "profiles/r03_rocprofv3_summary.txt (scripts/gpu_profile_r3.sh)"}
+             "source": f"profiles/{TAG}_rocprofv3_summary.txt (scripts/gpu_profile_{TAG[:1]}{int(TAG[1:])}.sh)"}
         f, nf = sums("pmc_fetch", k)
         w, nw = sums("pmc_write", k)
         if nf and nw:
@@ -115,5 +116,5 @@ for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_t
         if big:
             e["dispatches_over_1ms"] = big
         res[k] = e
-json.dump(res, open(os.path.join(out_dir, "r03_pmc.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out_dir, f"{TAG}_pmc.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
