@@ -452,6 +452,8 @@ def td_ragged_numbers(P=42, R=256, compare_per_matrix=True):
     counts = ragged_counts(P)
     psrs, noise = ragged_array(counts)
     eng = configure_engine(ReplicaEngine(psrs, seed=7), noise)
+    if os.environ.get("PTA_TD_POTRF_FLAGS"):              # A/B aid: chains / panel width / no look-ahead of the ragged schedule
+        eng.td_potrf_flags = int(os.environ["PTA_TD_POTRF_FLAGS"], 0)
     eng.prepare()
     eng.prepare_td()
     flop = sum(float(n) ** 3 for n in counts) / 3.0
@@ -537,6 +539,10 @@ def grid_cell(P, N, td=True, seed=20260921, td_gb_limit=200.0):
             cell["td"] = {"skipped": f"{gb:.0f} GB of factors do not fit beside the workspace"}
         else:
             try:
+                if os.environ.get("PTA_TD_POTRF_MODE"):      # A/B aid: "ragged" runs uniform batches through the end-aligned schedule too
+                    eng.td_potrf_mode = os.environ["PTA_TD_POTRF_MODE"]
+                if os.environ.get("PTA_TD_POTRF_FLAGS"):
+                    eng.td_potrf_flags = int(os.environ["PTA_TD_POTRF_FLAGS"], 0)
                 eng.prepare_td()
                 flop = P * float(N) ** 3 / 3.0
                 ta = min(_wall(eng.td_assemble) for _ in range(2))

@@ -430,9 +430,9 @@ typedef struct {
   const double *z;            /* ABI 3, rows_per_real == 1 only: NULL = every deviate is generated in registers (default); else the deviates
                                  are READ: z[m * ld_z + blk_zoff[b] + j] = deviate j of row m for factor block b - what pta_rng_fill_normal
                                  (interleave = 1) writes for stream (stream_kind, b).  Same numbers either way, bit-identical output.
-                                 Block b's deviates are whole pairs (blk_n[b] rounded up to even, at least 4 doubles) inside the row:
-                                 ld_z >= blk_zoff[b] + max(4, blk_n[b] + (blk_n[b] & 1)); nothing behind them is read (ABI 6: the
-                                 "16 finite doubles behind the last block" of ABI 5 is gone - the kernel clamps) */
+                                 A row must be READABLE up to blk_zoff[b] + blk_n[b] rounded up to a multiple of 4 (ld_z at least that);
+                                 what lies behind a block's blk_n[b] deviates is never used, finite or not (ABI 6: the "16 finite doubles
+                                 behind the last block" of ABI 5 is gone - the kernel clamps whole groups and zeroes k >= blk_n[b]) */
   int64_t ld_z;
   const int32_t *blk_zoff;    /* [n_blocks] first column of block b's deviates inside a row of z (even: pta_rng_fill_normal writes pairs) */
 } pta_td_plan;

@@ -401,9 +401,10 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   typedef double pta_f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
   const double *__restrict__ zrow = nullptr;
   pta_f64x2_a8 zn0 = {0.0, 0.0}, zn1 = {0.0, 0.0};
-  const int zlim = max(0, ((n + 1) & ~1) - 4);  // last k at which this lane's two pairs lie inside the block's own (whole) pairs
-  auto zfetch = [&](int k0) {  // a slab may reach up to 15 columns past the factor's order: those k are clamped back into the block's
-    const int kk = min(k0 + 4 * q, zlim);  // own deviates (finite; they multiply masked - zero - entries of L), so nothing behind the block is read
+  const int zlim = (n - 1) & ~3;  // the last 4-aligned group of k that holds a deviate of this block
+  auto zfetch = [&](int k0) {  // a slab may reach up to 15 columns past the factor's order: whole groups past the block are clamped back
+    const int kk = min(k0 + 4 * q, zlim);  // onto its last group (alignment kept: k0 + 4 q and zlim are multiples of 4), so at most the 3
+                                           // doubles that complete that group are read behind the block; their values never count (below)
     zn0 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk);
     zn1 = *reinterpret_cast<const pta_f64x2_a8 *>(zrow + kk + 2);
   };
@@ -418,6 +419,10 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
     double z[4];
     if (ZMEM) {
       z[0] = zn0.x, z[1] = zn0.y, z[2] = zn1.x, z[3] = zn1.y;
+      if (MASK) {  // k >= n: not a deviate of this block (clamped duplicates, the next block's, or row padding - possibly not even finite):
+#pragma unroll     // zeroed, so that 0 x NaN cannot reach an accumulator (diagonal slabs only: every k >= n lies behind the strip's diagonal)
+        for (int i = 0; i < 4; ++i) z[i] = (k0 + 4 * q + i < n) ? z[i] : 0.0;
+      }
       if (s + 1 < nslab) zfetch(k0 + TDS_K);
     } else {
       const uint32_t p0 = (uint32_t)((k0 >> 1) + 2 * q);

@@ -171,9 +171,11 @@ def _legacy_normals(seeds, counts):
 
 
 def _broadcast(val, P, what):
-    if isinstance(val, (list, tuple, np.ndarray)) and np.ndim(val) >= 1 and len(val) == P:
+    if isinstance(val, (list, tuple)) and len(val) == P:
         return list(val)
-    if val is None or np.isscalar(val) or np.ndim(val) == 0:
+    if isinstance(val, np.ndarray) and val.ndim >= 1 and len(val) == P:
+        return list(val)
+    if val is None or np.isscalar(val) or (isinstance(val, np.ndarray) and val.ndim == 0):
         return [val] * P
     raise ValueError(f"{what}: expected a scalar or one entry per pulsar ({P})")
 
