@@ -83,7 +83,7 @@ class TimeDomainMixin:
         else:
             self.tdgw_plan = None
             self.gw_td_jitter = 0.0
-        self._td_ws = None
+        self._td_bufs = None
         self._td_prepared = True
         return self
 
@@ -196,47 +196,90 @@ class TimeDomainMixin:
 
     # ---------------------------------------------------------------- generate ------------------
     def generate_td(self, R, r0=0, out=None, chunk=4096):
-        """out[R, n_toa] (device, seconds): realisations r0 .. r0+R-1 of the dense path, deviates drawn on chip."""
+        """out[R, n_toa] (device, seconds): realisations r0 .. r0+R-1 of the dense path, deviates drawn on chip.
+
+        The batch runs in chunks; ``td_overlap`` (default True, "memory" draws only) prepares chunk c + 1 - its deviates
+        (pta_rng_fill_normal_blocks) and its GWB grid series (the 600 x 600 factor's product + the ORF mix) - on a side stream while the
+        triangular product of chunk c occupies the matrix cores: the same kernels on the same counters, bit-identical output."""
         if not getattr(self, "_td_prepared", False) or not self._prepared:
             self.prepare_td()
         if out is None:
             out = dv.empty((R, self.n_toa))
-        s = dv.stream_ptr()
         P, npts = self.P, self.plan.gw_npts
         tp = self.td_plan
         tp.rng_fast = int(self.rng_fast)
         if self.tdgw_plan is not None:
             self.tdgw_plan.rng_fast = int(self.rng_fast)
-        chunk = int(min(chunk, R))
-        if npts:
-            ws = self._td_ws
-            if ws is None or ws[0].shape[0] < chunk:
-                ws = self._td_ws = (dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts)))
-            tp.gw_G = ws[1].data_ptr()
         # "memory" (default): the deviates of a batch are written once (pta_rng_fill_normal, 8 bytes each: 2.8 GB per 1024 realisations of
         # the 68 x 5000 array) and READ by the product; "registers": generated inside the product's loop (no buffer) - the same numbers,
         # bit-identical realisations; 31.2 against 35.0 ms per 1024 (the fp64 Box-Muller shares the double-precision ALUs with the MFMAs)
         zmem = getattr(self, "td_draws", "memory") == "memory"
-        if zmem:   # the deviates are written once per batch (8 bytes each) and READ by the product instead of being generated in its loop
+        overlap = zmem and bool(getattr(self, "td_overlap", True)) and R > int(getattr(self, "td_chunk", 256))
+        chunk = int(min(chunk, R))
+        if zmem:
             chunk = int(min(chunk, 1024))
+        if overlap:
+            chunk = int(min(chunk, getattr(self, "td_chunk", 256)))
+        nbuf = 2 if overlap else 1
+        bufs = getattr(self, "_td_bufs", None)
+        zcols = int(np.sum((self.counts + 1) // 2 * 2)) + 16
+        if bufs is None or len(bufs) < nbuf or bufs[0]["chunk"] < chunk or (zmem and bufs[0]["z"] is None):
+            bufs = []
+            for _ in range(nbuf):
+                b = {"chunk": chunk, "z": None, "G0": None, "G": None}
+                if npts:
+                    b["G0"], b["G"] = dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts))
+                if zmem:
+                    b["z"] = dv.zeros((chunk, zcols))
+                bufs.append(b)
+            self._td_bufs = bufs
             zoff = np.concatenate([[0], np.cumsum((self.counts + 1) // 2 * 2)]).astype(np.int64)   # every block starts on an even column
-            zb = getattr(self, "_td_zbuf", None)
-            if zb is None or zb.shape[0] < chunk or zb.shape[1] != int(zoff[-1]) + 16:
-                zb = self._td_zbuf = dv.zeros((chunk, int(zoff[-1]) + 16))
-                self._td_zoff = dv.i32(zoff[:-1])
-            tp.z, tp.ld_z, tp.blk_zoff = zb.data_ptr(), zb.stride(0), self._td_zoff.data_ptr()
-        else:
+            self._td_zoff = dv.i32(zoff[:-1])
+        if not zmem:
             tp.z, tp.ld_z, tp.blk_zoff = None, 0, None
-        for lo in range(0, R, chunk):
+        main = torch.cuda.current_stream()
+        s = ctypes.c_void_p(main.cuda_stream)
+        if overlap:
+            side = getattr(self, "_td_side", None)
+            if side is None:
+                side = self._td_side = torch.cuda.Stream()
+                self._td_ev = [[torch.cuda.Event() for _ in range(2)] for _ in range(2)]
+            ev_prep, ev_done = self._td_ev
+            side.wait_stream(main)
+        los = list(range(0, R, chunk))
+
+        def prepare_chunk(c, sp):
+            """deviates + GWB grid series of chunk c into buffer c & 1, on stream pointer sp"""
+            b, lo = bufs[c % nbuf], los[c]
             n = min(chunk, R - lo)
             if npts:
-                _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(ws[0]), npts, s)
-                _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(ws[0]), n, npts, npts, dv.ptr(ws[1]), int(self.mix_variant), s)
+                _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(b["G0"]), npts, sp)
+                _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(b["G0"]), n, npts, npts, dv.ptr(b["G"]), int(self.mix_variant), sp)
             if zmem:   # every pulsar's deviates of this chunk in one launch (stream (STREAM_TD, pulsar), as the register form draws them)
                 _lib.call("pta_rng_fill_normal_blocks", self.seed, r0 + lo, n, STREAM_TD, P, dv.ptr(self._td_layout[2]), dv.ptr(self._td_zoff),
-                          int(max(self.counts)), dv.ptr(zb), zb.stride(0), int(self.rng_fast), s)
+                          int(max(self.counts)), dv.ptr(b["z"]), b["z"].stride(0), int(self.rng_fast), sp)
+
+        for c, lo in enumerate(los):
+            b = bufs[c % nbuf]
+            n = min(chunk, R - lo)
+            if overlap:
+                k = c & 1
+                with torch.cuda.stream(side):
+                    if c >= 2:
+                        side.wait_event(ev_done[k])          # the product of chunk c - 2 has released this buffer
+                    prepare_chunk(c, ctypes.c_void_p(side.cuda_stream))
+                    ev_prep[k].record(side)
+                main.wait_event(ev_prep[k])
+            else:
+                prepare_chunk(c, s)
+            if npts:
+                tp.gw_G = b["G"].data_ptr()
+            if zmem:
+                tp.z, tp.ld_z, tp.blk_zoff = b["z"].data_ptr(), b["z"].stride(0), self._td_zoff.data_ptr()
             _lib.call("pta_td_trmm_rng", ctypes.byref(tp), self.seed, r0 + lo, n, ctypes.c_void_p(out.data_ptr() + 8 * lo * out.stride(0)),
                       out.stride(0), s)
+            if overlap:
+                ev_done[c & 1].record(main)
         return out
 
     # ---------------------------------------------------------------- draws / replay ------------
