@@ -198,9 +198,12 @@ class TimeDomainMixin:
     def generate_td(self, R, r0=0, out=None, chunk=4096):
         """out[R, n_toa] (device, seconds): realisations r0 .. r0+R-1 of the dense path, deviates drawn on chip.
 
-        The batch runs in chunks; ``td_overlap`` (default True, "memory" draws only) prepares chunk c + 1 - its deviates
+        The batch runs in chunks.  ``td_overlap = True`` (opt-in, "memory" draws only) prepares chunk c + 1 - its deviates
         (pta_rng_fill_normal_blocks) and its GWB grid series (the 600 x 600 factor's product + the ORF mix) - on a side stream while the
-        triangular product of chunk c occupies the matrix cores: the same kernels on the same counters, bit-identical output."""
+        triangular product of chunk c occupies the matrix cores: the same kernels on the same counters, bit-identical output.  Measured
+        and NOT the default (profiles/r04_bench_mid_round.json): 32.8 ms per 1024 realisations of the 68 x 5000 array in four pipelined
+        chunks of 256 against 31.2 ms as one chunk - every chunk streams the 13.6 GB of factors again, and the preparation kernels are
+        VALU work on the ALUs the matrix pipe shares, not idle time to fill."""
         if not getattr(self, "_td_prepared", False) or not self._prepared:
             self.prepare_td()
         if out is None:
@@ -214,7 +217,7 @@ class TimeDomainMixin:
         # the 68 x 5000 array) and READ by the product; "registers": generated inside the product's loop (no buffer) - the same numbers,
         # bit-identical realisations; 31.2 against 35.0 ms per 1024 (the fp64 Box-Muller shares the double-precision ALUs with the MFMAs)
         zmem = getattr(self, "td_draws", "memory") == "memory"
-        overlap = zmem and bool(getattr(self, "td_overlap", True)) and R > int(getattr(self, "td_chunk", 256))
+        overlap = zmem and bool(getattr(self, "td_overlap", False)) and R > int(getattr(self, "td_chunk", 256))
         chunk = int(min(chunk, R))
         if zmem:
             chunk = int(min(chunk, 1024))

@@ -57,15 +57,15 @@ def flag_codes(toas, flagid):
     """(labels, codes): ``labels[codes[i]]`` is the value of flag ``flagid`` of TOA i - what the reference rebuilds on every call
     as ``np.array([f[flagid] for f in toas.table['flags'].data])`` (white_noise.py:98-99,161; half of a call's time at 5000 TOAs).
     Built once per (TOA object, flagid) and cached on the object; flags are injection-invariant (adjust_TOAs does not touch them).
-    The cache is keyed by the TOA count and spot-checked against the live flags at 16 positions (ends, middle, a fixed pseudo-random
-    set).  INVARIANT the caller owns: flags edited in place between add_* calls are not seen - the reference re-reads them on every
+    The cache is keyed by the TOA count and spot-checked against the live flags at five positions (ends, middle, two fixed pseudo-random
+    ones).  INVARIANT the caller owns: flags edited in place between add_* calls are not seen - the reference re-reads them on every
     call - so after such an edit call ``clear_caches(psr)``; the errors column has no such caveat (content-checked)."""
     data = toas.table["flags"].data
     n = len(data)
     cache = getattr(toas, "_pta_flag_codes", None)
     hit = cache.get(flagid) if isinstance(cache, dict) else None
     if hit is not None and hit[0] == n and n > 0:
-        probe = {0, n // 2, n - 1} | {int(k) for k in (np.arange(1, 14) * 2654435761 % n)}
+        probe = (0, n // 2, n - 1, 2654435761 % n, 40503 * 7919 % n)
         if all(str(hit[1][hit[2][i]]) == str(data[i][flagid]) for i in probe):
             return hit[1], hit[2]
     col = np.array([f[flagid] for f in data])

@@ -378,10 +378,10 @@ def test_td_draws_from_memory_equal_draws_in_registers():
     assert torch.equal(eng.generate_td(9, r0=40), ref[35:44])
     eng.td_draws = "registers"
     assert torch.equal(eng.generate_td(70, r0=5), ref)
-    # chunks pipelined on a side stream (td_overlap, the default for batches larger than td_chunk): deviates + GWB grid series of
+    # chunks pipelined on a side stream (td_overlap, opt-in, for batches larger than td_chunk): deviates + GWB grid series of
     # chunk c + 1 prepared beside the product of chunk c, two buffers in rotation - the same realisations bit for bit, also when the
     # last chunk is short and when the buffers are re-used by a second call right behind the first
-    eng.td_draws, eng.td_chunk = "memory", 16
+    eng.td_draws, eng.td_chunk, eng.td_overlap = "memory", 16, True
     for _ in range(2):
         assert torch.equal(eng.generate_td(70, r0=5), ref)
     eng.td_overlap = False
