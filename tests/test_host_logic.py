@@ -469,3 +469,52 @@ def test_array_toas_float64_view_follows_the_toa_state():
     assert t.first_MJD.value == float(t.mjd_ld.min()) and t.last_MJD.value == float(t.mjd_ld.max())
     t.reset_ideal()
     assert np.array_equal(t.get_mjds().value, mjd) and t.first_MJD.value == mjd.min()
+
+
+def test_ragged_cholesky_plan_is_end_aligned_and_sorted():
+    """pta_potrf_ragged_plan (host code, no GPU): matrices sorted by decreasing order and dealt to the chains in turn; per chain the
+    virtual order E = NB (T_max + 1) of its largest matrix, per matrix front = E - n and a virtual offset such that virtual element
+    (front, front) is the matrix's own (0, 0); workspace = NB^2 doubles per matrix; odd orders / offsets / leading dimensions and
+    unsupported flags are refused."""
+    import ctypes
+    from pta_replicator_amd import _lib
+    n = np.array([300, 5000, 35038, 1024, 2050, 1026], dtype=np.int32)
+    ld = ((n + 15) // 16 * 16).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(n.astype(np.int64) * ld)])[:-1].astype(np.int64)
+    B = len(n)
+
+    def plan_for(flags):
+        plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(B)), dtype=np.int64)
+        need = ctypes.c_int64(0)
+        _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, flags, plan.ctypes.data, ctypes.byref(need))
+        return plan, need.value
+
+    for flags, nchain, NB in ((0, 2, 1024), (_lib.POTRF_CHAINS(3) | _lib.POTRF_NB(1), 3, 256), (_lib.POTRF_NO_LOOKAHEAD, 1, 1024)):
+        plan, need = plan_for(flags)
+        assert plan[1] == B and plan[3] == nchain and plan[4] == NB and plan[5] == need == B * NB * NB
+        order = sorted(range(B), key=lambda b: (-n[b], b))
+        seen = []
+        for c in range(nchain):
+            h = plan[8 + 8 * c: 16 + 8 * c]
+            Bc, E, Tmax, w0 = int(h[0]), int(h[1]), int(h[2]), int(h[3])
+            idx = plan[w0 + 3 * Bc: w0 + 4 * Bc]
+            assert list(idx) == order[c::nchain]                       # dealt in turn: every chain gets the same mix of orders
+            nn = plan[w0 + 4 * Bc: w0 + 5 * Bc]
+            assert list(nn) == [int(n[b]) for b in idx] and all(nn[k] >= nn[k + 1] for k in range(Bc - 1))
+            assert Tmax == (nn[0] - 1) // NB and E == NB * (Tmax + 1)
+            front = plan[w0 + 2 * Bc: w0 + 3 * Bc]
+            assert list(front) == [E - int(x) for x in nn]
+            offv, ldv = plan[w0: w0 + Bc], plan[w0 + Bc: w0 + 2 * Bc]
+            for k, b in enumerate(idx):
+                assert ldv[k] == ld[b] and offv[k] + front[k] * (ld[b] + 1) == off[b]      # virtual (front, front) = the matrix's (0, 0)
+            seen += list(idx)
+        assert sorted(seen) == list(range(B))
+    for bad in (dict(n=np.array([101], dtype=np.int32)), dict(ld=np.array([111], dtype=np.int64)), dict(off=np.array([3], dtype=np.int64))):
+        a = dict(n=np.array([100], dtype=np.int32), off=np.array([0], dtype=np.int64), ld=np.array([112], dtype=np.int64))
+        a.update(bad)
+        plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(1)), dtype=np.int64)
+        with pytest.raises(_lib.PtaError):
+            _lib.call("pta_potrf_ragged_plan", a["n"].ctypes.data, a["off"].ctypes.data, a["ld"].ctypes.data, 1, 0, plan.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
+    plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(B)), dtype=np.int64)
+    with pytest.raises(_lib.PtaError):   # the VALU / substitution cross-check paths have no ragged form
+        _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, _lib.POTRF_SUBSTITUTION, plan.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
