@@ -1293,8 +1293,12 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
     ch.ldw = NBO, ch.sW = (int64_t)NBO * NBO;
     ch.info = info;
     hipStream_t sc = nchain == 1 ? s : cx->chain[c];
-    if (nchain > 1) PTA_HIP(hipStreamWaitEvent(sc, cx->ev_in, 0));
-    if (la) PTA_HIP(hipStreamWaitEvent(cx->side[c], cx->ev_in, 0));
+    // (no early return from here on: the join below must run on every path)
+    if ((nchain > 1 && hipStreamWaitEvent(sc, cx->ev_in, 0) != hipSuccess) || (la && hipStreamWaitEvent(cx->side[c], cx->ev_in, 0) != hipSuccess)) {
+      pta_set_error("pta_potrf_ragged: hipStreamWaitEvent failed");
+      rc_chain = PTA_E_HIP;
+      break;
+    }
     rc_chain = pta_rag_chain_run(ch, sc, la ? cx->side[c] : nullptr, cx->ev_u1[c], cx->ev_la[c]);
   }
   if (nchain > 1)

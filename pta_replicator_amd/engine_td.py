@@ -65,6 +65,7 @@ class TimeDomainMixin:
         self._td_sigma2 = sigma2
         # block layout arrays (also what the product kernel reads)
         self._td_layout = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1])]
+        self._td_pad_idx = None
         self.td_assemble()
         self.td_factorise(lookahead=lookahead)
         blk, n0 = _strips(counts)
@@ -97,11 +98,18 @@ class TimeDomainMixin:
         _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
                   dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
                   dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
-        for a, n in enumerate(counts):
-            if n & 1:
-                row = self.d_Ltd[int(self.td_pos[a]) + n * self.td_ld[a]: int(self.td_pos[a]) + n * self.td_ld[a] + n + 1]
-                row.zero_()
-                row[n] = 1.0
+        pad = getattr(self, "_td_pad_idx", None)
+        if pad is None:   # the identity row of every odd order: positions of its zeros and of its one, built once per layout
+            rows, ones = [], []
+            for a, n in enumerate(counts):
+                if n & 1:
+                    start = int(self.td_pos[a]) + n * self.td_ld[a]
+                    rows.append(np.arange(start, start + n, dtype=np.int64))
+                    ones.append(start + n)
+            pad = self._td_pad_idx = (dv.i64(np.concatenate(rows)), dv.i64(ones)) if ones else ()
+        if pad:
+            self.d_Ltd.index_fill_(0, pad[0], 0.0)
+            self.d_Ltd.index_fill_(0, pad[1], 1.0)
 
     def td_factorise(self, lookahead=True, mode=None):
         """the batched factorisation of the assembled covariances, in place.  mode (default: attribute td_potrf_mode, "auto"):
@@ -251,16 +259,35 @@ class TimeDomainMixin:
             side.wait_stream(main)
         los = list(range(0, R, chunk))
 
+        # the deviate fill (VALU + stores) and the GWB grid stage (a small MFMA product + the ORF mix) of a chunk are independent: the fill
+        # goes to a second stream and is joined in front of the product (td_fill_beside_gwb, default on; same kernels, same counters)
+        beside = zmem and bool(npts) and not overlap and bool(getattr(self, "td_fill_beside_gwb", True))
+        if beside:
+            fstream = getattr(self, "_td_fill_stream", None)
+            if fstream is None:
+                fstream = self._td_fill_stream = torch.cuda.Stream()
+                self._td_fill_ev = torch.cuda.Event()
+
+        def fill_chunk(b, lo, n, sp):   # every pulsar's deviates of this chunk in one launch (stream (STREAM_TD, pulsar), as the register form draws them)
+            _lib.call("pta_rng_fill_normal_blocks", self.seed, r0 + lo, n, STREAM_TD, P, dv.ptr(self._td_layout[2]), dv.ptr(self._td_zoff),
+                      int(max(self.counts)), dv.ptr(b["z"]), b["z"].stride(0), int(self.rng_fast), sp)
+
         def prepare_chunk(c, sp):
             """deviates + GWB grid series of chunk c into buffer c & 1, on stream pointer sp"""
             b, lo = bufs[c % nbuf], los[c]
             n = min(chunk, R - lo)
+            if beside:
+                fstream.wait_stream(main)                    # behind the product that last read this Z buffer
+                with torch.cuda.stream(fstream):
+                    fill_chunk(b, lo, n, ctypes.c_void_p(fstream.cuda_stream))
+                    self._td_fill_ev.record(fstream)
             if npts:
                 _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(b["G0"]), npts, sp)
                 _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(b["G0"]), n, npts, npts, dv.ptr(b["G"]), int(self.mix_variant), sp)
-            if zmem:   # every pulsar's deviates of this chunk in one launch (stream (STREAM_TD, pulsar), as the register form draws them)
-                _lib.call("pta_rng_fill_normal_blocks", self.seed, r0 + lo, n, STREAM_TD, P, dv.ptr(self._td_layout[2]), dv.ptr(self._td_zoff),
-                          int(max(self.counts)), dv.ptr(b["z"]), b["z"].stride(0), int(self.rng_fast), sp)
+            if beside:
+                main.wait_event(self._td_fill_ev)
+            elif zmem:
+                fill_chunk(b, lo, n, sp)
 
         for c, lo in enumerate(los):
             b = bufs[c % nbuf]
