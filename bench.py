@@ -331,10 +331,6 @@ def td_mode_numbers(eng, R):
     eng.generate_td(R, out=out)
     t_overlap = wall(lambda: eng.generate_td(R, out=out), 2)
     eng.td_overlap = False                      # default: one chunk, deviates and GWB grid series in front of the product
-    eng.td_fill_beside_gwb = False              # A/B: the deviate fill in line behind the GWB grid stage (round 3)
-    eng.generate_td(R, out=out)
-    t_inline = wall(lambda: eng.generate_td(R, out=out), 3)
-    eng.td_fill_beside_gwb = True               # default: the fill on a second stream beside the GWB grid stage
     eng.generate_td(R, out=out)
     t = wall(lambda: eng.generate_td(R, out=out), 3)
     flop = float(sum(n * n for n in counts))       # useful flops per realisation of L.z (triangular): sum N_a^2
@@ -347,7 +343,7 @@ def td_mode_numbers(eng, R):
     res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
                 "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "td_draws": "memory (deviates written once per batch, read by the product)",
-                "generate_td_ms_with_chunk_overlap_opt_in": t_overlap * 1e3, "generate_td_ms_fill_in_line": t_inline * 1e3,
+                "generate_td_ms_with_chunk_overlap_opt_in": t_overlap * 1e3,
                 "draws_in_registers": {"generate_td_ms": t_reg * 1e3, "realisations_per_s": R / t_reg, "trmm_useful_TFLOPs": flop * R / t_reg / 1e12},
                 "gw_grid_factor_jitter": eng.gw_td_jitter if eng.plan.gw_npts else None})
     # MFMA-busy % from the committed PMC pass: the tile product over its dispatches of >= 1 ms (the trailing updates; the mean over all

@@ -192,7 +192,7 @@ int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, 
  * Matrix b: order n[b], row-major lower triangle at A + off[b], leading dimension ld[b]; n, off, ld are HOST arrays, all entries
  * EVEN (16-byte operand rows: pad an odd order with an identity row / column at its end) and ld[b] >= n[b].
  * The matrices are end-aligned: embedded in a virtual matrix whose bottom-right corner they share, so that at every time step
- * (one panel of NB = 1024 columns counted from the END) all matrices that have been reached have the same panel boundaries,
+ * (one panel of NB columns counted from the END; NB = 1024, or 2048 when the flop-weighted mean order is >= 16384, or PTA_POTRF_NB) all matrices that have been reached have the same panel boundaries,
  * trailing size and tile grids - every kernel of the step is one launch over them; a matrix enters at the step that contains its
  * first column, with the panel cut at its front (masked inside the kernels).  The diagonal phases (latency chains) are paid once
  * per time step instead of once per matrix and panel.  Chains / look-ahead / workspace scheme as pta_potrf_batched_ws.

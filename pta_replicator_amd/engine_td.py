@@ -260,8 +260,9 @@ class TimeDomainMixin:
         los = list(range(0, R, chunk))
 
         # the deviate fill (VALU + stores) and the GWB grid stage (a small MFMA product + the ORF mix) of a chunk are independent: the fill
-        # goes to a second stream and is joined in front of the product (td_fill_beside_gwb, default on; same kernels, same counters)
-        beside = zmem and bool(npts) and not overlap and bool(getattr(self, "td_fill_beside_gwb", True))
+        # can go to a second stream and be joined in front of the product (td_fill_beside_gwb, opt-in; same kernels, same counters;
+        # measured 31.26 against 31.27 ms per 1024 realisations of the 68 x 5000 array: nothing to gain, off by default)
+        beside = zmem and bool(npts) and not overlap and bool(getattr(self, "td_fill_beside_gwb", False))
         if beside:
             fstream = getattr(self, "_td_fill_stream", None)
             if fstream is None:

@@ -301,6 +301,7 @@ def _spd(rng, n):
     ((1500, 258, 700, 256, 254, 1280, 1282, 66, 1024, 512, 130), "NB1C3"),
     ((2200, 2200, 2200), "NB1"),                                           # a uniform batch is the special case front = const
     ((4200, 3100, 600), "NB2"),
+    ((4200, 3100, 600, 2050), "NB8"),                                       # 2048-column panels (the default for arrays of large matrices)
     ((5000,), 0),                                                           # a batch of one
 ])
 def test_potrf_ragged_vs_numpy(gpu, orders, flags):
@@ -310,7 +311,7 @@ def test_potrf_ragged_vs_numpy(gpu, orders, flags):
     matrices smaller than one block."""
     lib = gpu["lib"]
     fl = {0: 0, "C1": lib.POTRF_CHAINS(1), "NOLA": lib.POTRF_NO_LOOKAHEAD, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3),
-          "NB2": lib.POTRF_NB(2)}[flags]
+          "NB2": lib.POTRF_NB(2), "NB8": lib.POTRF_NB(8)}[flags]
     rng = np.random.default_rng(sum(orders))
     mats = [_spd(rng, n) for n in orders]
     Ls, info = _ragged_factor(gpu, mats, fl)

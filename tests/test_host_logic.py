@@ -489,7 +489,8 @@ def test_ragged_cholesky_plan_is_end_aligned_and_sorted():
         _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, flags, plan.ctypes.data, ctypes.byref(need))
         return plan, need.value
 
-    for flags, nchain, NB in ((0, 2, 1024), (_lib.POTRF_CHAINS(3) | _lib.POTRF_NB(1), 3, 256), (_lib.POTRF_NO_LOOKAHEAD, 1, 1024)):
+    # (the default panel is 2048 columns here: the flop-weighted mean order of these six matrices is 35 000; 1024 below 16 384)
+    for flags, nchain, NB in ((0, 2, 2048), (_lib.POTRF_CHAINS(3) | _lib.POTRF_NB(1), 3, 256), (_lib.POTRF_NO_LOOKAHEAD | _lib.POTRF_NB(4), 1, 1024)):
         plan, need = plan_for(flags)
         assert plan[1] == B and plan[3] == nchain and plan[4] == NB and plan[5] == need == B * NB * NB
         order = sorted(range(B), key=lambda b: (-n[b], b))
