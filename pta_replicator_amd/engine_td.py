@@ -143,13 +143,15 @@ class TimeDomainMixin:
             # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.2 ms against 56.5 ms
             # without; td_potrf_workspace = False keeps the workspace-free two-chain schedule.
             use_ws = bool(getattr(self, "td_potrf_workspace", True))
-            flags = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
-            flags |= extra
+            flags0 = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
+            flags0 |= extra
             a = 0
             while a < P:
                 b = a
                 while b + 1 < P and nst[b + 1] == nst[a]:
                     b += 1
+                # panels of 2048 columns for large matrices (as the ragged schedule's default): half as many passes over the trailing matrix
+                flags = flags0 | (_lib.POTRF_NB(8) if (use_ws and nst[a] >= 16384 and not (flags0 >> 8) & 0xFF) else 0)
                 need = int(_lib.lib.pta_potrf_workspace_doubles(nst[a], b - a + 1, flags)) if use_ws else 0
                 work = dv.empty((need,)) if need else None
                 _lib.call("pta_potrf_batched_ws", ctypes.c_void_p(self.d_Ltd.data_ptr() + 8 * int(pos[a])), nst[a], ld[a],
