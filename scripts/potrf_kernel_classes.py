@@ -3,6 +3,7 @@ schedule goes.  usage: potrf_kernel_classes.py <trace dir> [first|last]  (which 
 import collections, csv, glob, sys
 
 root = sys.argv[1]
+PT = next((int(a[3:]) for a in sys.argv[2:] if a.startswith("pt=")), 16)   # 128-column tiles per panel: 16 = 2048-column panels (the default for large matrices), 8 = 1024
 rows = []
 for p in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(p)))
@@ -13,7 +14,7 @@ cov = [i for i, r in enumerate(rows) if "k_td_cov128" in r["Kernel_Name"]]
 names = ("k_diag128", "k_ws_strips", "k_dgemm_glds128", "k_dgemm_mfma<", "k_potf2", "k_trsm", "k_syrk64", "k_inv_blocks")
 if not cov:
     sys.exit("no assembly launch found in the trace")
-pick = cov[0] if (len(sys.argv) > 2 and sys.argv[2] == "first") else cov[-1]
+pick = cov[0] if "first" in sys.argv[2:] else cov[-1]
 seg = []
 for r in rows[pick + 1:]:
     if any(n in r["Kernel_Name"] for n in names):
@@ -34,14 +35,15 @@ def cls(r):
     if "k_dgemm_mfma<" in k:
         return "diagonal phase: 64-tile products (rows below a group, < 256 rows)"
     if "k_dgemm_glds128" in k:
-        if gy == 1 and gx > 36:
-            return "trailing updates (lower-triangular tile products, K = 1024)"
-        if gy == 1:
-            return "next panel's diagonal block of the trailing update (U1, 36 tiles per matrix)"
-        if gx == 8:
+        u1 = PT * (PT + 1) // 2
+        if gy == 1 and gx > u1:
+            return f"trailing updates (lower-triangular tile products, K = {128 * PT})"
+        if gy == 1 and gx == u1:
+            return f"next panel's diagonal block of the trailing update (U1, {u1} tiles per matrix)"
+        if gx == PT and gy >= PT:
             return "trailing updates: sub-diagonal rectangle of the next panel (U2a)"
-        if gx == 1 and gy >= 8:
-            return "substitution on the rows below the panel (one product per 128-column block, K = 128 .. 1024)"
+        if gx == 1 and gy >= PT:
+            return f"substitution on the rows below the panel (one product per 128-column block, K = 128 .. {128 * PT})"
         return "diagonal phase: 128-tile products of the recursion"
     return "other potrf kernels (" + k.replace("void ", "")[:24] + ")"
 
