@@ -286,11 +286,17 @@ def td_mode_numbers(eng, R):
             wall(assemble)
             ts_free.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
             bad += int(info.abs().sum().item())
+        ts_epi = []
         for _ in range(4):
             ta = wall(assemble)
             ts.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD,
                                              dv.ptr(work), need, s)))
             bad += int(info.abs().sum().item())
+            wall(assemble)   # A/B: the tile products' C-tile prefetch epilogue (PTA_POTRF_EPI1)
+            ts_epi.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD | _lib.POTRF_EPI1,
+                                                 dv.ptr(work), need, s)))
+            bad += int(info.abs().sum().item())
+        res["potrf_epi1_ms"] = min(ts_epi) * 1e3
         info.add_(bad)
         del work
         tp = min(ts)

@@ -170,6 +170,8 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 #define PTA_POTRF_DIAG64 16         /* A/B (workspace scheme): the panel's diagonal block by the 64-column recursion (k_potf2 / k_trsm_mfma /
                                      k_syrk64) + one inversion pass instead of the 128-column base case k_diag128 */
 #define PTA_POTRF_LOCKSTEP 64       /* A/B (workspace scheme): all chains start together instead of one diagonal phase apart */
+#define PTA_POTRF_EPI1 0x100000     /* A/B: the 128 x 128-tile products prefetch their C tile behind the last slab and store interior tiles
+                                       unpredicated (pta_dgemm algo 3; also honoured by pta_potrf_ragged_plan) */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 /* The same factorisation with a caller-owned workspace (device memory, `work_doubles` doubles, at least
@@ -468,7 +470,7 @@ int pta_gather_rank0(void *comm, int rank, int world, int dst, const double *loc
 /* C[b] = alpha * A[b] * op(B[b]) + beta * C[b], row-major, batch `batch` with element strides.
  * A element (m,k) = A[m*lda + k*ska] (ska = 2 reads the real or imaginary plane of interleaved
  * complex rows); transB = 0: B is [K x N]; 1: B is [N x K].  lower_only = 1 touches only col <= row
- * (SYRK).  algo 0 = VALU reference kernel, 1 = v_mfma_f64_16x16x4_f64 kernel, 2 = the MFMA kernel whose 128 x 128-tile form stages
+ * (SYRK).  algo 0 = VALU reference kernel, 1 = v_mfma_f64_16x16x4_f64 kernel, 2 (3: with the C-tile prefetch epilogue, A/B) = the MFMA kernel whose 128 x 128-tile form stages
  * its operand slabs by LDS DMA (transB = 1, ska = 1, even K / lda / ldb / strides, 16-byte aligned A and B; else as algo 1). */
 int pta_dgemm(int transB, int M, int N, int K, double alpha, const double *A, int64_t lda, int64_t ska,
               const double *B, int64_t ldb, double beta, double *C, int64_t ldc, int lower_only, int batch,

@@ -54,6 +54,7 @@ struct pta_rag {
   const int64_t *off;
   const int64_t *ld;
   const int64_t *front;
+  int epi;  // host side: 1 = the tile products' EPI = 1 form (PTA_POTRF_EPI1, A/B)
 };
 // C[r0 + m, c0 + n] = alpha * sum_k A[r0 + m, k0 + k] * Bop[n, k] + beta * C[...] for every matrix b < batch of a ragged batch (m < M,
 // n < N, k < K in virtual coordinates, masked below front[b]); Bop[n, k] = the matrix's own element [c0 + n, k0 + k] when Bws is NULL,

@@ -30,7 +30,7 @@ template <bool BT, bool RAG = false>
 __global__ __launch_bounds__(256) void k_dgemm_mfma(int M, int N, int K, double alpha, const double *__restrict__ A,
                                                     int64_t lda, int64_t ska, const double *__restrict__ B, int64_t ldb,
                                                     double beta, double *__restrict__ C, int64_t ldc, int lower_only,
-                                                    int64_t sA, int64_t sB, int64_t sC, pta_rag rg = pta_rag{nullptr, nullptr, nullptr},
+                                                    int64_t sA, int64_t sB, int64_t sC, pta_rag rg = pta_rag{nullptr, nullptr, nullptr, 0},
                                                     int r0 = 0, int c0 = 0, int kv0 = 0, int bws = 0) {
   const int bm = blockIdx.y, bn = blockIdx.x;
   if (lower_only && bn * GBN > bm * GBM + (GBM - 1)) return;  // tile entirely above the diagonal
@@ -356,7 +356,10 @@ __device__ __forceinline__ int pta_gl_f(int row) {
 // offset / leading dimension; rows < mbeg, columns < nbeg and k < kbeg (= below the matrix's `front`) are masked: DMA sources clamped into
 // the valid range, the fragments of masked k slots zeroed in the one slab that straddles kbeg (the K loop starts at that slab), stores
 // predicated; tiles wholly below the front leave at once.  The uniform instantiation carries none of it.
-template <bool RAG>
+// EPI = 1 (A/B, PTA_POTRF_EPI1 / pta_dgemm algo 3): the C tile's first 16 elements per lane are requested BEFORE the last slab's products and
+// every later batch before the previous batch's stores (two register sets in rotation), and a tile that no bound, mask or diagonal cuts
+// stores unpredicated - the epilogue's four dependent load round trips become one that the last 64 MFMAs cover.
+template <bool RAG, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, double alpha, const double *__restrict__ A, int64_t lda,
                                                           const double *__restrict__ B, int64_t ldb, double beta, double *__restrict__ C,
                                                           int64_t ldc, int lower_only, int64_t sA, int64_t sB, int64_t sC, pta_rag rg, int r0,
@@ -487,27 +490,71 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
   };
   const int nfull = K / GBK, ktail = K - nfull * GBK, nslab = nfull + (ktail ? 1 : 0);
   const int s0 = RAG ? kbeg / GBK : 0;  // first slab with a valid k
+  const int colb = n0 + wn * 64 + pta_mfma_col(l);
+  // C element (batch i, column tile j, register r) of this lane, from a clamped - always valid - address
+  auto c_load = [&](int i, double (&cv)[4][4]) {
+    const int rowb = m0 + wm * 64 + i * 16 + (l >> 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cv[j][r] = C[(int64_t)min(RAG ? max(rowb + 4 * r, mbeg) : rowb + 4 * r, M - 1) * ldc + min(RAG ? max(colb + j * 16, nbeg) : colb + j * 16, N - 1)];
+  };
+  double cva[4][4], cvb[4][4];
+  const bool has_c = beta != 0.0;
   if (!RAG || s0 < nslab) {
     stage(s0 * GBK, s0 & 1);
     __syncthreads();  // drains the DMA (vmcnt(0)) before any wave reads the slab
-    for (int sidx = s0; sidx < nfull; ++sidx) {
-      slab_product(sidx & 1, GBK, sidx + 1 < nslab ? (sidx + 1) * GBK : -1, (RAG && sidx == s0) ? kbeg - s0 * GBK : 0);
-      __syncthreads();  // every wave is done reading this slab; the DMA of the next one has landed
+    if (EPI) {
+      const int last = nslab - 1;  // the last slab (a K tail, or the last full one) runs behind the C prefetch
+      for (int sidx = s0; sidx < last; ++sidx) {
+        slab_product(sidx & 1, GBK, (sidx + 1) * GBK, (RAG && sidx == s0) ? kbeg - s0 * GBK : 0);
+        __syncthreads();
+      }
+      if (has_c) c_load(0, cva);
+      slab_product(last & 1, ktail ? ktail : GBK, -1, (RAG && last == s0) ? kbeg - s0 * GBK : 0);
+    } else {
+      for (int sidx = s0; sidx < nfull; ++sidx) {
+        slab_product(sidx & 1, GBK, sidx + 1 < nslab ? (sidx + 1) * GBK : -1, (RAG && sidx == s0) ? kbeg - s0 * GBK : 0);
+        __syncthreads();  // every wave is done reading this slab; the DMA of the next one has landed
+      }
+      if (ktail) slab_product(nfull & 1, ktail, -1, (RAG && nfull == s0) ? kbeg - s0 * GBK : 0);
     }
-    if (ktail) slab_product(nfull & 1, ktail, -1, (RAG && nfull == s0) ? kbeg - s0 * GBK : 0);
+  } else if (EPI && has_c) {
+    c_load(0, cva);
   }
-  const int colb = n0 + wn * 64 + pta_mfma_col(l);
+  if (EPI) {
+    // workgroup-uniform: no row / column bound, no ragged mask and no diagonal cuts this tile
+    const bool interior = m0 + HBM_T <= M && n0 + HBM_T <= N && (!RAG || (mbeg <= m0 && nbeg <= n0)) && (!lower_only || n0 + HBM_T - 1 <= m0);
+    auto c_store = [&](int i, const double (&cv)[4][4]) {
+      const int rowb = m0 + wm * 64 + i * 16 + (l >> 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rowb + 4 * r, col = colb + j * 16;
+          double v = alpha * acc[i][j][r];
+          if (has_c) v = fma(beta, cv[j][r], v);
+          if (interior)
+            C[(int64_t)row * ldc + col] = v;
+          else if (row < M && col < N && (!RAG || (row >= mbeg && col >= nbeg)) && (!lower_only || col <= row))
+            C[(int64_t)row * ldc + col] = v;
+        }
+    };
+    if (has_c) c_load(1, cvb);
+    c_store(0, cva);
+    if (has_c) c_load(2, cva);
+    c_store(1, cvb);
+    if (has_c) c_load(3, cvb);
+    c_store(2, cva);
+    c_store(3, cvb);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rowb = m0 + wm * 64 + i * 16 + (l >> 4);
     double cv[4][4];
-    if (beta != 0.0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cv[j][r] = C[(int64_t)min(RAG ? max(rowb + 4 * r, mbeg) : rowb + 4 * r, M - 1) * ldc + min(RAG ? max(colb + j * 16, nbeg) : colb + j * 16, N - 1)];
-    }
+    if (beta != 0.0) c_load(i, cv);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -568,10 +615,11 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
     }
     const bool vec = transB && ska == 1 && (K % 2) == 0 && (lda % 2) == 0 && (ldb % 2) == 0 && (sA % 2) == 0 && (sB % 2) == 0 &&
                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
-    if (vec && algo == 2)
-      hipLaunchKernelGGL(k_dgemm_glds128<false>, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, lower_only, sA, sB, sC,
-                         pta_rag{nullptr, nullptr, nullptr}, 0, 0, 0, 0);
-    else if (vec)
+    if (vec && algo >= 2) {
+      auto kern = algo == 3 ? k_dgemm_glds128<false, 1> : k_dgemm_glds128<false, 0>;
+      hipLaunchKernelGGL(kern, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,
+                         lower_only, sA, sB, sC, pta_rag{nullptr, nullptr, nullptr, 0}, 0, 0, 0, 0);
+    } else if (vec)
       hipLaunchKernelGGL((k_dgemm_mfma128<true, true>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
     else if (transB)
       hipLaunchKernelGGL((k_dgemm_mfma128<true, false>), g, dim3(256), 0, stream, M, N, K, alpha, A, lda, ska, B, ldb, beta, C, ldc, lower_only, sA, sB, sC);
@@ -605,7 +653,8 @@ int pta_dgemm_launch_rag(int M, int N, int K, double alpha, double *Abase, int r
       g = dim3(nt * (nt + 1) / 2, 1, batch);
       lower_only = 2;
     }
-    hipLaunchKernelGGL(k_dgemm_glds128<true>, g, dim3(256), 0, stream, M, N, K, alpha, Abase, (int64_t)0, B, ldb, beta, Abase, (int64_t)0, lower_only,
+    auto kern = rg.epi ? k_dgemm_glds128<true, 1> : k_dgemm_glds128<true, 0>;
+    hipLaunchKernelGGL(kern, g, dim3(256), 0, stream, M, N, K, alpha, Abase, (int64_t)0, B, ldb, beta, Abase, (int64_t)0, lower_only,
                        (int64_t)0, sB, (int64_t)0, rg, r0, c0, k0, bws);
   } else {
     PTA_REQUIRE(pta_cdiv(M, GBM) <= 65535u, PTA_E_ARG, "pta_dgemm_rag: M=%d too large", M);

@@ -854,7 +854,7 @@ static int pta_factor_diag_ws(double *A, int pend, int64_t lda, int64_t sA, int 
     const int oj = c0 - p.k0;                                   // offset inside the panel: 0 for the first block, f128 + 128 (j - 1) after
     const int j = oj == 0 ? 0 : (oj - p.f128) / 128 + 1;
     double *Wjj = W + (int64_t)j * 128 * ldw + oj;
-    hipLaunchKernelGGL(k_diag128<false>, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, Wjj, ldw, sW, info, pta_rag{nullptr, nullptr, nullptr}, nullptr);
+    hipLaunchKernelGGL(k_diag128<false>, dim3(B), dim3(256), 0, sp, A, lda, sA, c0, w, Wjj, ldw, sW, info, pta_rag{nullptr, nullptr, nullptr, 0}, nullptr);
     PTA_LAUNCH_CHECK();
     const int rows = pend - c0 - w;
     if (rows <= 0) return PTA_OK;
@@ -890,7 +890,7 @@ static int pta_ws_diag_phase(double *A, int64_t lda, int64_t strideA, int B, int
   if (p.nb > 1) {
     int groups = 0;
     for (int j = 1; j < p.nb; ++j) groups += ((p.f128 + 128 * (j - 1) + 63) / 64 + PTA_WS_STRIP_GROUP - 1) / PTA_WS_STRIP_GROUP;
-    hipLaunchKernelGGL(k_ws_strips<false>, dim3(groups, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.f128, W, ldw, sW, pta_rag{nullptr, nullptr, nullptr});
+    hipLaunchKernelGGL(k_ws_strips<false>, dim3(groups, B), dim3(256), 0, s, A, lda, strideA, p.k0, p.f128, W, ldw, sW, pta_rag{nullptr, nullptr, nullptr, 0});
     PTA_LAUNCH_CHECK();
   }
   return PTA_OK;
@@ -994,7 +994,7 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   // 0: VALU reference GEMM + substitution panel solve (cross-check); 2 (default): MFMA kernels, the 128 x 128-tile products' operand
   // slabs brought in by LDS DMA (k_dgemm_glds128: 66 against 59 TFLOP/s at K = 1024, the whole 68 x 5000^2 batch 56.4 against 60.0
   // ms); 1 (PTA_POTRF_REG_STAGING): the same products with register-staged slabs (round 2's kernel, kept for the A/B)
-  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_REG_STAGING) ? 1 : 2);
+  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_REG_STAGING) ? 1 : ((flags & PTA_POTRF_EPI1) ? 3 : 2));
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
@@ -1299,7 +1299,7 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
     ch.A = A;
     ch.Bc = (int)h[0], ch.E = (int)h[1], ch.Tmax = (int)h[2], ch.NBO = NBO;
     const int64_t *d = plan_dev + h[3];
-    ch.rg = pta_rag{d, d + ch.Bc, d + 2 * ch.Bc};
+    ch.rg = pta_rag{d, d + ch.Bc, d + 2 * ch.Bc, (flags & PTA_POTRF_EPI1) ? 1 : 0};
     ch.idx = d + 3 * ch.Bc;
     ch.n = plan + h[3] + 4 * ch.Bc;
     ch.W = work + h[4];

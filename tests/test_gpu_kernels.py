@@ -136,7 +136,7 @@ def test_dgemm_mfma_and_valu(gpu, shape, transB):
         assert np.max(np.abs(Cd.cpu().numpy() - ref)) < 1e-11 * max(1.0, np.max(np.abs(ref))), (algo, shape)
 
 
-@pytest.mark.parametrize("shape", [(256, 128, 32), (300, 257, 76), (515, 400, 64), (1000, 520, 1032), (640, 640, 250)])
+@pytest.mark.parametrize("shape", [(256, 128, 32), (300, 257, 76), (515, 400, 64), (1000, 520, 1032), (640, 640, 250), (768, 384, 16), (512, 256, 8)])
 @pytest.mark.parametrize("lower", [0, 1])
 def test_dgemm_lds_dma_operand_staging(gpu, shape, lower):
     """pta_dgemm algo 2 (k_dgemm_glds128: operand slabs by global_load_lds, swizzled LDS image, permuted k slots) against NumPy and
@@ -153,7 +153,7 @@ def test_dgemm_lds_dma_operand_staging(gpu, shape, lower):
     C0 = rng.standard_normal((Bt, M, N))
     ref = 0.7 * A[:, :, 4:4 + K] @ Bm[:, :, 2:2 + K].transpose(0, 2, 1) - 1.3 * C0
     got = {}
-    for algo in (1, 2):
+    for algo in (1, 2, 3):        # 3 = the same kernel with the C-tile prefetch epilogue (A/B form, PTA_POTRF_EPI1)
         Ad, Bd, Cd = dv.f64(A), dv.f64(Bm), dv.f64(C0)
         lib.call("pta_dgemm", 1, M, N, K, 0.7, ctypes.c_void_p(Ad.data_ptr() + 8 * 4), lda, 1, ctypes.c_void_p(Bd.data_ptr() + 8 * 2), ldb, -1.3,
                  dv.ptr(Cd), N, lower, Bt, M * lda, N * ldb, M * N, algo, gpu["s"])
@@ -224,7 +224,7 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
 
 
 @pytest.mark.parametrize("n,batch,flags", [(1025, 2, 0), (1338, 3, 0), (2500, 2, 0), (2501, 1, 0), (700, 3, "NB1"), (1338, 3, "NB1"), (2500, 2, "NB1C3"),
-                                           (3000, 5, "C4"), (3000, 2, "LA"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1"), (2500, 2, "D64"), (2501, 2, "NB1D64LA"), (1200, 3, "LA"), (1290, 2, 0)])
+                                           (3000, 5, "C4"), (3000, 2, "LA"), (3000, 2, "LAEPI1"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1"), (2500, 2, "D64"), (2501, 2, "NB1D64LA"), (1200, 3, "LA"), (1290, 2, 0)])
 def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
     over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
@@ -232,7 +232,7 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
     fl = {0: 0, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3), "C4": lib.POTRF_CHAINS(4),
           # look-ahead of the next panel's diagonal phase on a side stream (used while >= 1536 rows remain below it)
-          "LA": lib.POTRF_DIAG_AHEAD, "NB1LA": lib.POTRF_NB(1) | lib.POTRF_DIAG_AHEAD, "NB1C3LA": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3) | lib.POTRF_DIAG_AHEAD,
+          "LA": lib.POTRF_DIAG_AHEAD, "LAEPI1": lib.POTRF_DIAG_AHEAD | lib.POTRF_EPI1, "NB1LA": lib.POTRF_NB(1) | lib.POTRF_DIAG_AHEAD, "NB1C3LA": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3) | lib.POTRF_DIAG_AHEAD,
           "NB2LA1": lib.POTRF_NB(2) | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(1),
           # A/B path: 64-column recursion on the diagonal block + inversion pass
           "D64": lib.POTRF_DIAG64, "NB1D64LA": lib.POTRF_NB(1) | lib.POTRF_DIAG64 | lib.POTRF_DIAG_AHEAD}[flags]
@@ -303,6 +303,7 @@ def _spd(rng, n):
     ((4200, 3100, 600), "NB2"),
     ((4200, 3100, 600, 2050), "NB8"),                                       # 2048-column panels (the default for arrays of large matrices)
     ((5000,), 0),                                                           # a batch of one
+    ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), "EPI1"),       # tile products with the C-tile prefetch epilogue (A/B form)
 ])
 def test_potrf_ragged_vs_numpy(gpu, orders, flags):
     """pta_potrf_ragged: matrices of different orders as ONE end-aligned schedule (red_noise.py:286-298 loops pulsars; a real array has
@@ -311,7 +312,7 @@ def test_potrf_ragged_vs_numpy(gpu, orders, flags):
     matrices smaller than one block."""
     lib = gpu["lib"]
     fl = {0: 0, "C1": lib.POTRF_CHAINS(1), "NOLA": lib.POTRF_NO_LOOKAHEAD, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3),
-          "NB2": lib.POTRF_NB(2), "NB8": lib.POTRF_NB(8)}[flags]
+          "NB2": lib.POTRF_NB(2), "NB8": lib.POTRF_NB(8), "EPI1": lib.POTRF_EPI1}[flags]
     rng = np.random.default_rng(sum(orders))
     mats = [_spd(rng, n) for n in orders]
     Ls, info = _ragged_factor(gpu, mats, fl)
