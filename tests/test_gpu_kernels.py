@@ -534,3 +534,21 @@ def test_gwb_mix_against_numpy(gpu, P, npts, R, ldg, variant):
     ref = np.einsum("ab,rbj->raj", M, G0[:, :, :npts])
     assert np.max(np.abs(G[:, :, :npts] - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
     assert np.all(G[:, :, npts:] == 7.0)            # padding columns untouched
+
+
+def test_clock_probe_measures_a_plausible_engine_clock(gpu):
+    """pta_clock_probe: (s_memrealtime, s_memtime) pairs from one wave on a side stream; the slope is the engine clock."""
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    ns = 64
+    buf = torch.zeros((ns, 2), dtype=torch.int64, device="cuda")
+    side = torch.cuda.Stream()
+    lib.call("pta_clock_probe", buf.data_ptr(), ns, 20000, 500, side.cuda_stream)       # 20 ms, one sample per 0.5 ms
+    side.synchronize()
+    s = buf.cpu().numpy()
+    s = s[s[:, 0] > 0]
+    assert 30 <= len(s) <= ns
+    assert np.all(np.diff(s[:, 0]) > 0) and np.all(np.diff(s[:, 1]) > 0)
+    ghz = np.diff(s[:, 1]) / (np.diff(s[:, 0]) * 10.0)                                # cycles per 10 ns tick of the 100 MHz reference
+    assert 0.05 < np.median(ghz) < 3.5, np.median(ghz)
+    with pytest.raises(lib.PtaError):
+        lib.call("pta_clock_probe", None, ns, 1000, 100, None)
