@@ -303,6 +303,7 @@ def _spd(rng, n):
     ((4200, 3100, 600), "NB2"),
     ((4200, 3100, 600, 2050), "NB8"),                                       # 2048-column panels (the default for arrays of large matrices)
     ((5000,), 0),                                                           # a batch of one
+    ((778, 90, 1026, 2602), 0),                                             # the TD test array's orders (cuts 10 / 2 / 90 columns wide)
     ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), "EPI1"),       # tile products with the C-tile prefetch epilogue (A/B form)
 ])
 def test_potrf_ragged_vs_numpy(gpu, orders, flags):
