@@ -271,16 +271,6 @@ def td_mode_numbers(eng, R):
         _lib.call("pta_td_cov_assemble_all", dv.ptr(eng.d_Ft), eng.n_toa, eng.K, dv.ptr(phi), dv.ptr(eng._td_sigma2), dv.ptr(eng.d_epoch_of), dv.ptr(ec2),
                   dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), s)
 
-    def assemble_v(variant):
-        _lib.call("pta_td_cov_assemble_all_ex", dv.ptr(eng.d_Ft), eng.n_toa, eng.K, dv.ptr(phi), dv.ptr(eng._td_sigma2), dv.ptr(eng.d_epoch_of), dv.ptr(ec2),
-                  dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), variant, s)
-    cov_ab = {}
-    try:   # A/B of the two assembly kernels: 1 = 64 x 128 tiles through LDS, 2 = column-walking waves with the operand of their columns in registers
-        for v, name in ((1, "tile_kernel_ms"), (2, "column_walking_kernel_ms")):
-            wall(lambda: assemble_v(v))
-            cov_ab[name] = min(wall(lambda: assemble_v(v), 3) for _ in range(2)) * 1e3
-    except Exception as e:  # pragma: no cover
-        cov_ab["error"] = str(e)[:200]
     uniform = len(set(counts)) == 1
     res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_warm * 1e3, "prepare_td_first_call_ms": t_first * 1e3,
            "factor_buffer_alloc_ms": t_alloc * 1e3, "factor_buffer_GB": nbytes / 1e9}
@@ -356,7 +346,6 @@ def td_mode_numbers(eng, R):
         res["trmm_frac_at_measured_clock"] = flop * R / t / 1e12 / (FP64_MFMA_PEAK_TFLOPS * ck["GHz"] / 2.4)
         if res.get("potrf_engine_clock_GHz") and res.get("potrf_TFLOPs"):
             res["potrf_frac_at_measured_clock"] = res["potrf_TFLOPs"] / (FP64_MFMA_PEAK_TFLOPS * res["potrf_engine_clock_GHz"] / 2.4)
-    res["cov_assemble_kernels"] = cov_ab
     res.update({"generate_td_realisations": R, "generate_td_ms": t * 1e3, "realisations_per_s": R / t,
                 "trmm_useful_TFLOPs": flop * R / t / 1e12, "trmm_frac_of_fp64_mfma_peak": flop * R / t / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                 "td_draws": "memory (deviates written once per batch, read by the product)",

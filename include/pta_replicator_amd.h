@@ -390,13 +390,6 @@ int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *
                             const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                             const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
                             void *stream);
-/* The same with a choice of kernel (ABI 6): variant 0 = default, 1 = the 64 x 128-tile kernel (operand slabs through LDS), 2 = the
- * column-walking kernel (a wave keeps the phi-scaled operand of its 32 columns in registers and walks down the rows: no LDS, no
- * barrier; needs 56 < K <= 64, i.e. 29 ... 32 red-noise components).                                                                  */
-int pta_td_cov_assemble_all_ex(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
-                               const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
-                               const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
-                               int variant, void *stream);
 
 /* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or

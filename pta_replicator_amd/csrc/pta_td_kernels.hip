@@ -264,135 +264,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
   }
 }
 
-// ---- column-walking assembly (round 4; VERDICT r2 / r3: the tile kernel above sits at 53 % MFMA-busy, 2.3 TB/s written) ----------------
-// The tile kernel re-fetches BOTH operand slabs for every 64 x 128 tile (92 KB of L2 reads per 64 KB written) and pays a load -> LDS ->
-// barrier round per 16-k slab.  Here a wave OWNS 32 columns of one pulsar's covariance for a whole segment of rows: its B operand -
-// phi_k F[k, col], 2 column tiles x NKS k-steps - is loaded ONCE into registers (60 VGPRs at K = 60) and stays there while the wave walks
-// down the rows 32 at a time; the A operand of a step is 2 x NKS fragment loads straight from the K-major design matrix (a lane's value
-// F[4 ks + (l >> 4), row0 + (l & 15)]: four 128-byte row pieces per instruction, L1 hits for the three sibling waves that walk the same
-// rows), 60 MFMAs, then the white / ECORR terms and the stores.  No LDS, no barrier: the waves of a workgroup only share their rows (L1
-// locality); two waves per SIMD overlap one's loads with the other's products.  Work item = (pulsar, 128-column strip, segment of
-// TCW_SEG rows below the strip's diagonal); K <= 4 NKS.
-#define TCW_SEG 512
-#define PTA_TD_COV_DEFAULT_WALK 0   // variant 0 takes the tile kernel until the column-walking kernel has been measured faster
-template <int NKS>
-__global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
-                                                        const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
-                                                        const double *__restrict__ ecorr2, double *__restrict__ Cbase,
-                                                        const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
-                                                        const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off) {
-  const int blk = blockIdx.y;
-  const int N = blk_n[blk];
-  int item = blockIdx.x, cs = 0;
-  const int nstrip = (N + 127) >> 7;
-  for (; cs < nstrip; ++cs) {  // item -> (strip, segment); workgroup-uniform
-    const int ns = (N - 128 * cs + TCW_SEG - 1) / TCW_SEG;
-    if (item < ns) break;
-    item -= ns;
-  }
-  if (cs >= nstrip) return;
-  const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = l & 15, lq = l >> 4;
-  const int c0 = 128 * cs + 32 * w;  // this wave's 32 columns
-  if (c0 >= N) return;
-  const int rbeg = 128 * cs + TCW_SEG * item, rend = min(N, rbeg + TCW_SEG);
-  const int64_t off = blk_off[blk];
-  const int64_t ldc = blk_ld[blk];
-  double *__restrict__ C = Cbase + blk_pos[blk];
-  const double *__restrict__ F = Ft + off;
-  const double *__restrict__ ph = phi + (int64_t)blk * K;
-  // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, c0 + 16 jt + li]; k >= K enters as zero
-  double b[2][NKS];
-  int ccol[2], ecol[2];
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt) {
-    const int col = c0 + 16 * jt + li;
-    ccol[jt] = min(col, N - 1);
-    ecol[jt] = (epoch_of && col < N) ? epoch_of[off + col] : -1;
-  }
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    const int k = 4 * ks + lq, kc = min(k, K - 1);
-    const double p = k < K ? ph[kc] : 0.0;
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) b[jt][ks] = p * F[(int64_t)kc * ldf + ccol[jt]];
-  }
-  const int64_t kbase = (int64_t)lq * ldf;  // this lane's k row inside a k-step
-  for (int r0 = max(rbeg, c0); r0 < rend; r0 += 32) {  // wave-uniform; rows above the wave's own columns are not in the lower triangle
-    int rowc[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) rowc[it] = min(r0 + 16 * it + li, N - 1);
-    double a[2][NKS];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-      const double *__restrict__ Fk = F + kbase + (int64_t)min(4 * ks, K - 1 - lq < 0 ? 0 : 4 * ks) * ldf;  // (k clamped below; a masked k meets b = 0)
-#pragma unroll
-      for (int it = 0; it < 2; ++it) a[it][ks] = Fk[rowc[it]];
-    }
-    // the epilogue's per-row operands, requested beside the fragments: epoch, ECORR variance and (diagonal steps) white variance
-    const bool diag_step = r0 < c0 + 32;  // wave-uniform
-    int erow[2][4];
-    double e2[2][4], s2[2][4];
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = min(r0 + 16 * it + pta_mfma_row(l, r), N - 1);
-        erow[it][r] = epoch_of ? epoch_of[off + row] : -2;
-        e2[it][r] = epoch_of ? ecorr2[off + row] : 0.0;
-        s2[it][r] = diag_step ? sigma2[off + row] : 0.0;
-      }
-    pta_f64x4 acc[2][2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt) acc[it][jt] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks)
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt) acc[it][jt] = pta_mfma_f64(a[it][ks], b[jt][ks], acc[it][jt]);
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = r0 + 16 * it + pta_mfma_row(l, r), col = c0 + 16 * jt + li;
-          double v = acc[it][jt][r];
-          if (diag_step && row == col) v = v + s2[it][r];
-          if (erow[it][r] == ecol[jt] && col <= row) v = v + e2[it][r];
-          if (row < N && col <= row) C[(int64_t)row * ldc + col] = v;
-        }
-  }
-}
-
-extern "C" int pta_td_cov_assemble_all_ex(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
-                                          const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
-                                          const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
-                                          int variant, void *stream) {
+extern "C" int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
+                                       const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
+                                       const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
+                                       void *stream) {
   PTA_REQUIRE(sigma2 && Cbase && blk_pos && blk_ld && blk_n && blk_off && (K == 0 || (Ft && phi)), PTA_E_ARG,
               "pta_td_cov_assemble_all: NULL argument");
   PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble_all: ecorr2 missing");
   PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && max_n > 0 && K >= 0, PTA_E_ARG, "pta_td_cov_assemble_all: n_blocks=%d max_n=%d K=%d",
               n_blocks, max_n, K);
   PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_all: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
-  PTA_REQUIRE(variant >= 0 && variant <= 2, PTA_E_ARG, "pta_td_cov_assemble_all_ex: variant=%d (0 = default, 1 = tile kernel, 2 = column-walking kernel)", variant);
-  const bool walk_ok = K > 56 && K <= 64;  // the resident operand of the column-walking kernel is compiled for 15 / 16 k-steps (components = 29 ... 32)
-  PTA_REQUIRE(variant != 2 || walk_ok, PTA_E_ARG, "pta_td_cov_assemble_all_ex: the column-walking kernel needs 56 < K <= 64 (K=%d)", K);
-  if (variant == 2 || (variant == 0 && walk_ok && PTA_TD_COV_DEFAULT_WALK)) {
-    int64_t items = 0;
-    for (int cs = 0; 128 * cs < max_n; ++cs) items += (max_n - 128 * cs + TCW_SEG - 1) / TCW_SEG;
-    PTA_REQUIRE(items < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_all: max_n=%d too large", max_n);
-    if (K <= 60)
-      hipLaunchKernelGGL(k_td_cov_walk<15>, dim3((unsigned)items, n_blocks), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2,
-                         Cbase, blk_pos, blk_ld, blk_n, blk_off);
-    else
-      hipLaunchKernelGGL(k_td_cov_walk<16>, dim3((unsigned)items, n_blocks), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2,
-                         Cbase, blk_pos, blk_ld, blk_n, blk_off);
-    PTA_LAUNCH_CHECK();
-    return PTA_OK;
-  }
   const int64_t nt = pta_cdiv(max_n, TC_T);
   PTA_REQUIRE(nt * (nt + 1) < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_all: max_n=%d too large", max_n);
   // 64-row tiles (row blocks 2 p, 2 p + 1 x column tiles 0 .. p), three workgroups per CU: 2.97 ms for the 68 x 5000^2 lower triangles
@@ -401,13 +282,6 @@ extern "C" int pta_td_cov_assemble_all_ex(const double *Ft, int64_t ldf, int K, 
                      epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
-}
-
-extern "C" int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
-                                       const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
-                                       const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
-                                       void *stream) {
-  return pta_td_cov_assemble_all_ex(Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, n_blocks, max_n, 0, stream);
 }
 
 // out[r, i] (+)= sum_j z[r, j] L[i, j]  =  (Z . L^T)[r, i]; L's strict upper triangle is zero.

@@ -95,9 +95,9 @@ class TimeDomainMixin:
         K = pl.rn_k
         phi = (self.d_amp ** 2).contiguous() if K else None
         ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
-        _lib.call("pta_td_cov_assemble_all_ex", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
+        _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
                   dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
-                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), int(getattr(self, "td_cov_variant", 0)), s)
+                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
         pad = getattr(self, "_td_pad_idx", None)
         if pad is None:   # the identity row of every odd order: positions of its zeros and of its one, built once per layout
             rows, ones = [], []

@@ -388,46 +388,3 @@ def test_td_draws_from_memory_equal_draws_in_registers():
     assert torch.equal(eng.generate_td(70, r0=5), ref)
     eng.td_fill_beside_gwb = True         # opt-in: the deviate fill on a second stream beside the GWB grid stage
     assert torch.equal(eng.generate_td(70, r0=5), ref)
-
-
-@pytest.mark.parametrize("components", [30, 32, 29])
-def test_td_covariance_column_walking_kernel_equals_the_tile_kernel(components):
-    """pta_td_cov_assemble_all_ex variant 2 (a wave keeps the phi-scaled operand of its 32 columns in registers and walks down the rows;
-    K = 60 / 64 / 58: whole and cut k-steps) against variant 1 (64 x 128 tiles through LDS) on ragged pulsars with odd counts, a count below
-    one strip, multi-TOA ECORR epochs and a pulsar without red noise: the lower triangles agree to rounding (phi enters on the other
-    operand), and nothing outside them is written."""
-    import torch
-    from pta_replicator_amd.engine import ReplicaEngine
-    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
-    rng = np.random.default_rng(components)
-    psrs = []
-    for a, n in enumerate((777, 90, 1025, 2601)):
-        ep = np.sort(rng.uniform(53000, 56000, n // 3 + 1))
-        mjd = (ep[:, None] + rng.uniform(0, 0.01, (len(ep), 3))).ravel()[:n]          # ~3 TOAs per ECORR epoch
-        p = SimulatedPulsar(toas=ArrayTOAs(mjd, rng.uniform(0.3, 1.5, n)), name=f"J{a:04d}", loc={"RAJ": 2.0 + 3 * a, "DECJ": -20.0 + 25 * a})
-        make_ideal(p)
-        psrs.append(p)
-    eng = ReplicaEngine(psrs, seed=3)
-    eng.set_white_noise(efac=1.1, log10_equad=-6.3)
-    eng.set_jitter(log10_ecorr=-6.5, coarsegrain=0.1)
-    eng.set_red_noise([-13.6, None, -14.0, -13.2], [3.1, None, 4.2, 2.2], components=components)
-    eng.prepare().prepare_td()
-    got = {}
-    for variant in (1, 2):
-        eng.td_cov_variant = variant
-        eng.d_Ltd.fill_(float("nan"))
-        eng.td_assemble()
-        got[variant] = eng.d_Ltd.clone()
-    for a in range(eng.P):
-        n, ld, pos = int(eng.counts[a]), eng.td_ld[a], int(eng.td_pos[a])
-        v1 = got[1][pos:pos + n * ld].view(n, ld)[:, :n].cpu().numpy()
-        v2 = got[2][pos:pos + n * ld].view(n, ld)[:, :n].cpu().numpy()
-        lo = np.tril_indices(n)
-        assert np.all(np.isfinite(v2[lo]))
-        assert np.max(np.abs(v1[lo] - v2[lo])) < 1e-13 * np.max(np.abs(v1[lo])), a
-        up = np.triu_indices(n, 1)
-        assert np.all(np.isnan(v2[up]))                                                 # the upper triangle is not touched
-    eng.td_cov_variant = 2
-    eng.prepare_td()                                                                    # and the factorisation is happy with it
-    out = eng.generate_td(3)
-    assert bool(torch.isfinite(out).all())
