@@ -324,6 +324,27 @@ def test_potrf_ragged_vs_numpy(gpu, orders, flags):
         assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (b, orders[b], flags)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_potrf_ragged_random_order_sets(gpu, seed):
+    """random batches (1 ... 9 matrices, even orders 2 ... 3000, any mix of equal and different orders) under a random choice of
+    panel width / chains / look-ahead: every factor against LAPACK."""
+    lib = gpu["lib"]
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.integers(1, 10))
+    orders = [2 * int(x) for x in rng.integers(1, 1501, B)]
+    if seed % 3 == 0 and B > 2:
+        orders[1] = orders[0]                      # equal orders share a time step from their first panel on
+    flags = [0, lib.POTRF_NB(1), lib.POTRF_NB(2) | lib.POTRF_CHAINS(3), lib.POTRF_NO_LOOKAHEAD, lib.POTRF_NB(8), lib.POTRF_NB(3) | lib.POTRF_CHAINS(4),
+             lib.POTRF_NB(1) | lib.POTRF_CHAINS(1), lib.POTRF_EPI1 | lib.POTRF_NB(2)][seed % 8]
+    mats = [_spd(rng, n) for n in orders]
+    Ls, info = _ragged_factor(gpu, mats, flags)
+    assert not info.any(), (orders, info)
+    for b, (L, m) in enumerate(zip(Ls, mats)):
+        ref = np.linalg.cholesky(m)
+        assert np.all(np.isfinite(L)), (b, orders)
+        assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (b, orders, flags)
+
+
 def test_potrf_ragged_reports_the_first_bad_pivot_of_the_right_matrix(gpu):
     """info[b] in the caller's order and in the matrix's own numbering (LAPACK convention), whatever chain / time step the pivot falls in."""
     rng = np.random.default_rng(5)
