@@ -66,7 +66,14 @@ class TimeDomainMixin:
         # block layout arrays (also what the product kernel reads)
         self._td_layout = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1])]
         self._td_pad_idx = None
+        # one-off path: the host waits for the operands it has just computed (sigma2, the layout arrays) before the assembly is queued and
+        # for the assembly before the factorisation's internal streams are fed.  Stream order already guarantees both (measured:
+        # scripts/gpu_r4_stream_order.py); the two waits cost nothing next to a 57 ms factorisation and keep an unexplained observation
+        # of this round (a withdrawn assembly kernel produced NaN in one launch sequence until a device-wide
+        # synchronisation) from ever mattering here.  td_assemble() / td_factorise() themselves stay asynchronous.
+        torch.cuda.current_stream().synchronize()
         self.td_assemble()
+        torch.cuda.current_stream().synchronize()
         self.td_factorise(lookahead=lookahead)
         blk, n0 = _strips(counts)
         self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0)]
