@@ -1285,6 +1285,20 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
   PTA_REQUIRE(work_doubles >= plan[5], PTA_E_ARG, "pta_potrf_ragged: workspace of %lld doubles, %lld needed", (long long)work_doubles, (long long)plan[5]);
   PTA_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)work % 16) == 0, PTA_E_ARG, "pta_potrf_ragged: A and work must be 16-byte aligned");
   const int B = (int)plan[1], flags = (int)plan[2], nchain = (int)plan[3], NBO = (int)plan[4];
+  PTA_REQUIRE(B > 0 && B <= 65535 && nchain >= 1 && nchain <= PTA_POTRF_MAX_CHAINS && nchain <= B && NBO >= 128 && NBO <= 16384 && NBO % 128 == 0 &&
+                  plan[6] == pta_potrf_ragged_plan_words(B),
+              PTA_E_ARG, "pta_potrf_ragged: inconsistent plan header (B=%d chains=%d panel=%d words=%lld)", B, nchain, NBO, (long long)plan[6]);
+  {
+    int64_t seen = 0;
+    for (int c = 0; c < nchain; ++c) {
+      const int64_t *h = plan + PTA_RAG_HDR + PTA_RAG_CHDR * c;
+      PTA_REQUIRE(h[0] > 0 && h[0] <= B && h[3] >= PTA_RAG_HDR + PTA_RAG_CHDR * PTA_POTRF_MAX_CHAINS && h[3] + 5 * h[0] <= plan[6] && h[1] == (int64_t)NBO * (h[2] + 1) &&
+                      h[4] >= 0 && h[4] + h[0] * (int64_t)NBO * NBO <= plan[5],
+                  PTA_E_ARG, "pta_potrf_ragged: inconsistent plan (chain %d)", c);
+      seen += h[0];
+    }
+    PTA_REQUIRE(seen == B, PTA_E_ARG, "pta_potrf_ragged: the plan's chains hold %lld of %d matrices", (long long)seen, B);
+  }
   hipStream_t s = pta_stream(stream);
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   pta_potrf_ctx *cx = nullptr;

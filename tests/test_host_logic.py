@@ -516,6 +516,13 @@ def test_ragged_cholesky_plan_is_end_aligned_and_sorted():
         plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(1)), dtype=np.int64)
         with pytest.raises(_lib.PtaError):
             _lib.call("pta_potrf_ragged_plan", a["n"].ctypes.data, a["off"].ctypes.data, a["ld"].ctypes.data, 1, 0, plan.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
+    # a tampered plan is refused before anything is launched (header and per-chain consistency checks; no GPU needed to see it)
+    plan, need = plan_for(0)
+    for word, value in ((0, 1), (3, 7), (4, 1000), (8, B + 1), (9, 12345)):
+        bad = plan.copy()
+        bad[word] = value
+        rc = _lib.lib.pta_potrf_ragged(ctypes.c_void_p(16), bad.ctypes.data, ctypes.c_void_p(16), ctypes.c_void_p(16), ctypes.c_void_p(16), need, None)
+        assert rc == -1 and "plan" in _lib.last_error(), (word, rc, _lib.last_error())
     plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(B)), dtype=np.int64)
     with pytest.raises(_lib.PtaError):   # the VALU / substitution cross-check paths have no ragged form
         _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, _lib.POTRF_SUBSTITUTION, plan.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
