@@ -345,6 +345,24 @@ def test_potrf_ragged_random_order_sets(gpu, seed):
         assert np.max(np.abs(L - ref)) < 1e-10 * np.max(np.abs(ref)), (b, orders, flags)
 
 
+def test_potrf_ragged_is_deterministic_and_independent_of_the_batch(gpu):
+    """two chains, look-ahead on side streams, matrices entering at different steps - and still: the same input gives the same bits
+    run after run, and a matrix's factor does not depend on which other matrices share its batch (no atomics, no order-dependent sums)."""
+    lib = gpu["lib"]
+    rng = np.random.default_rng(77)
+    orders = (2300, 600, 1400, 2300, 130)
+    mats = [_spd(rng, n) for n in orders]
+    a, info = _ragged_factor(gpu, mats, 0)
+    b, _ = _ragged_factor(gpu, mats, 0)
+    assert not info.any()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    alone, _ = _ragged_factor(gpu, [mats[2]], 0)
+    assert np.array_equal(alone[0], a[2])
+    other, _ = _ragged_factor(gpu, [mats[4], mats[2], mats[0]], lib.POTRF_CHAINS(1))
+    assert np.array_equal(other[1], a[2]) and np.array_equal(other[0], a[4])
+
+
 def test_potrf_ragged_reports_the_first_bad_pivot_of_the_right_matrix(gpu):
     """info[b] in the caller's order and in the matrix's own numbering (LAPACK convention), whatever chain / time step the pivot falls in."""
     rng = np.random.default_rng(5)
