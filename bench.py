@@ -453,14 +453,15 @@ def engine_clock_during(fn, seconds=0.5):
             "method": "pta_clock_probe: s_memtime / s_memrealtime slope, 100 us samples on a side stream beside the loop"}
 
 
-def td_ragged_numbers(P=42, R=256, compare_per_matrix=True):
+def td_ragged_numbers(P=42, R=256, compare_per_matrix=True, counts=None):
     """TD mode on an ng15-like RAGGED array (VERDICT r3 #1b): TOA counts log-uniform 500 ... 35 000, sum = 340 k - the normal shape of real
     data (the reference loops over pulsars: red_noise.py:286-298).  `potrf` = ALL pulsars as one end-aligned schedule (pta_potrf_ragged);
     `per_matrix` = the batch-by-equal-order scheme of rounds 1-3 on the same array (P batches of one)."""
     import torch
     from pta_replicator_amd.engine import ReplicaEngine
     from pta_replicator_amd import device as dv
-    counts = ragged_counts(P)
+    counts = ragged_counts(P) if counts is None else [int(c) for c in counts]
+    P = len(counts)
     psrs, noise = ragged_array(counts)
     eng = configure_engine(ReplicaEngine(psrs, seed=7), noise)
     if os.environ.get("PTA_TD_POTRF_FLAGS"):              # A/B aid: chains / panel width / no look-ahead of the ragged schedule
@@ -898,6 +899,13 @@ def main():
                     td["ragged"]["potrf_TFLOPs_over_uniform_68x5000"] = td["ragged"]["potrf_TFLOPs"] / td["potrf_TFLOPs"]
             except Exception as e:  # pragma: no cover
                 td["ragged"] = {"error": str(e)[:300]}
+            torch.cuda.empty_cache()
+            try:   # BASELINE.json config 2's SHAPE in TD mode: the TOA counts of the reference's test_partim set (par/*.par:17), 256 realisations
+                td["config2_shape"] = dict(td_ragged_numbers(R=256, compare_per_matrix=False, counts=(7758, 23023, 35037)),
+                                           workload="TOA counts of test_partim (B1855+09 7758, B1937+21 23023, J1909-3744 35037; two of them odd), synthetic TOAs, "
+                                                    "ng15 noise values cycled; parity on the real tim file: tests/test_gpu_configs.py::test_config2_td_mode")
+            except Exception as e:  # pragma: no cover
+                td["config2_shape"] = {"error": str(e)[:300]}
             torch.cuda.empty_cache()
 
     # ---- four cells of the (N_psr, N_toa) grid the north_star asks for (the full grid: scripts/gpu_grid_sweep.py -> profiles/r04_grid.json) ----
