@@ -526,3 +526,19 @@ def test_ragged_cholesky_plan_is_end_aligned_and_sorted():
     plan = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(B)), dtype=np.int64)
     with pytest.raises(_lib.PtaError):   # the VALU / substitution cross-check paths have no ragged form
         _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, _lib.POTRF_SUBSTITUTION, plan.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
+
+
+def test_bench_ragged_workload_definition():
+    """bench.ragged_counts: the ng15-like spread of TOA counts the ragged TD figures are quoted on (42 quantiles of the log-uniform
+    distribution on [500, 35000]: sum 340 915 = the headline array's total, 46.9 TFLOP of factorisation), shuffled but reproducible;
+    bench.ragged_array builds pulsars of exactly those counts with the ng15 noise values cycled."""
+    import bench
+    c = bench.ragged_counts()
+    assert len(c) == 42 and sum(c) == 340915 and min(c) == 526 and max(c) == 33274
+    assert c == bench.ragged_counts() and c != sorted(c) and c != sorted(c, reverse=True)
+    assert abs(sum(float(n) ** 3 for n in c) / 3 / 1e12 - 46.9146) < 1e-3
+    psrs, noise = bench.ragged_array(c[:3])
+    assert [p.toas.ntoas for p in psrs] == c[:3]
+    assert len(noise["efac"]) == 3 and len(noise["flags"][0]) == len(noise["efac"][0])
+    for p, fl in zip(psrs, noise["flags"]):
+        assert {f["f"] for f in p.toas.flags} <= set(fl)
