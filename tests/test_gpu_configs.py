@@ -278,3 +278,18 @@ def test_config5_ska_scale_anisotropic():
         worst = max(worst, relrms(out[1, eng.off[a]:eng.off[a + 1]], ref))
     assert worst < 1e-10, worst
     _fused_equals_replay(eng, 1)
+
+
+def test_bench_helpers_small_shapes():
+    """the functions the bench line is assembled from (grid cells, ragged TD numbers) on small shapes: every key the line carries is there
+    and finite - the driver's bench run depends on them."""
+    import bench
+    c = bench.grid_cell(3, 122, td=True)
+    t, d = c["throughput"], c["td"]
+    assert t["realisations_per_s"] > 0 and 0 < t["tile_fill"] <= 1 and t["dominant_kernel"] in t["kernels_ms"]
+    assert d["finite"] and d["potrf_ms"] > 0 and d["realisations_per_s"] > 0 and d["schedule"] == "uniform"
+    r = bench.td_ragged_numbers(R=32, counts=(600, 1301, 2050, 130))
+    assert r["schedule"] == "ragged" and r["finite"] and r["potrf_TFLOPs"] > 0 and r["per_matrix_schedule"]["potrf_ms"] > 0
+    assert r["n_toa_total"] == 600 + 1301 + 2050 + 130
+    ck = bench.engine_clock_during(lambda: bench.grid_cell, 0.05)      # a no-op load: the probe alone
+    assert ck is None or 0.05 < ck["GHz"] < 3.5
