@@ -267,16 +267,25 @@ def td_mode_numbers(eng, R):
     phi = (eng.d_amp ** 2).contiguous()
     ec2 = (eng.d_ecorr_toa ** 2).contiguous()
 
-    def assemble():
-        _lib.call("pta_td_cov_assemble_all", dv.ptr(eng.d_Ft), eng.n_toa, eng.K, dv.ptr(phi), dv.ptr(eng._td_sigma2), dv.ptr(eng.d_epoch_of), dv.ptr(ec2),
-                  dv.ptr(eng.d_Ltd), *[dv.ptr(x) for x in eng._td_layout], eng.P, max(counts), s)
+    assemble = eng.td_assemble     # the engine's default assembly kernel (column-walking where 1 <= K <= 64, else 64 x 128 tiles)
 
     uniform = len(set(counts)) == 1
     res = {"n_psr": eng.P, "n_toa": counts[0] if uniform else counts, "prepare_td_ms": t_warm * 1e3, "prepare_td_first_call_ms": t_first * 1e3,
            "factor_buffer_alloc_ms": t_alloc * 1e3, "factor_buffer_GB": nbytes / 1e9}
     flop_chol = sum(n ** 3 for n in counts) / 3.0
+    # the assembly alone, both kernels, against the ALGORITHMIC bytes (8 per element of the lower triangles, diagonal included)
+    cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
+    for kname in ("walk", "tile"):
+        try:
+            eng.td_assemble(kernel=kname)
+            tk = min(wall(lambda: eng.td_assemble(kernel=kname)) for _ in range(4))
+            res[f"cov_assemble_{kname}_ms"] = tk * 1e3
+            res[f"cov_assemble_{kname}_TBps"] = cov_bytes / tk / 1e12
+        except Exception as e:  # pragma: no cover
+            res[f"cov_assemble_{kname}_error"] = str(e)[:200]
+    res["cov_assemble_kernel"] = getattr(eng, "td_cov_kernel_used", None)
     if uniform:
-        n, ld, P = counts[0], eng.td_ld[0], eng.P
+        n, ld, P = eng.td_nst[0], eng.td_ld[0], eng.P   # stored order: an odd TOA count carries one identity row / column (engine_td.prepare_td)
         info = dv.zeros((P,), dtype=torch.int32)
         # the schedule prepare_td() uses (workspace scheme, next panel's diagonal phase run ahead) and the workspace-free two-chain one
         need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, _lib.POTRF_DIAG_AHEAD))
@@ -323,7 +332,7 @@ def td_mode_numbers(eng, R):
         if ck:
             res["potrf_engine_clock_GHz"] = ck["GHz"]
         eng.prepare_td()
-        res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_GBps_lower_triangle": 8.0 * sum(n * (n + 64) / 2 for n in counts) / ta / 1e9,
+        res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_GBps_lower_triangle": cov_bytes / ta / 1e9,
                     "potrf_ms": tp * 1e3, "potrf_TFLOPs": flop_chol / tp / 1e12, "potrf_frac_of_fp64_mfma_peak": flop_chol / tp / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                     "positive_definite": int(info.abs().sum().item()) == 0})
     out = dv.empty((R, eng.n_toa))
@@ -472,7 +481,13 @@ def td_ragged_numbers(P=42, R=256, compare_per_matrix=True, counts=None):
     res = {"n_psr": P, "n_toa_min": min(counts), "n_toa_max": max(counts), "n_toa_total": int(sum(counts)), "factor_buffer_GB": eng.d_Ltd.numel() * 8 / 1e9,
            "potrf_TFLOP": flop / 1e12, "schedule": eng.td_potrf_mode_used}
     ta = min(_wall(eng.td_assemble) for _ in range(2))
-    res["cov_assemble_ms"] = ta * 1e3
+    cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)       # algorithmic: the lower triangles, written once
+    res.update({"cov_assemble_ms": ta * 1e3, "cov_assemble_kernel": getattr(eng, "td_cov_kernel_used", None), "cov_assemble_TBps": cov_bytes / ta / 1e12})
+    try:   # the tile kernel on the same array (its grid is sized by the LARGEST pulsar: most workgroups of a ragged launch leave at once)
+        tt = min(_wall(lambda: eng.td_assemble(kernel="tile")) for _ in range(2))
+        res.update({"cov_assemble_tile_ms": tt * 1e3, "cov_assemble_tile_TBps": cov_bytes / tt / 1e12})
+    except Exception as e:  # pragma: no cover
+        res["cov_assemble_tile_error"] = str(e)[:200]
 
     def timed_factor(mode):
         ts = []
@@ -579,6 +594,125 @@ def grid_cell(P, N, td=True, seed=20260921, td_gb_limit=200.0):
     del eng
     torch.cuda.empty_cache()
     return cell
+
+
+def orf_numbers(P=200, lmax=4, reps=5):
+    """the anisotropic ORF basis of BASELINE config 5's geometry (200 pulsars, l <= 4: all 20 100 pairs x 25 modes - 12-15 minutes of
+    Python in the reference, spharmORFbasis.py:385-434): HIP events around pta_orf_basis and pta_orf_combine on the
+    stream they are launched on, the host's pair-separation loop (the reference's own scalar arithmetic, kept on the host) timed beside them"""
+    import torch
+    from pta_replicator_amd import _lib, device as dv, spharmORFbasis as anis
+    rng = np.random.default_rng(200)
+    raj, decj = rng.uniform(0, 24, P), np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
+    locs = np.ascontiguousarray(np.stack([raj * np.pi / 12.0, np.pi / 2.0 - np.radians(decj)], axis=1))
+    t0 = time.perf_counter()
+    zc = anis.pair_zeta_cos(locs)
+    t_host = time.perf_counter() - t0
+    locs_d, zc_d = dv.f64(locs), dv.f64(zc)
+    nb = (lmax + 1) ** 2
+    basis, orf = dv.zeros((nb, P, P)), dv.empty((P, P))
+    clm = dv.f64(np.concatenate([[np.sqrt(4 * np.pi)], 0.1 * np.random.default_rng(200).standard_normal(nb - 1)]))
+    s = dv.stream_ptr()
+
+    def ev_time(fn):
+        fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        for _ in range(reps):
+            fn()
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / reps
+
+    tb = ev_time(lambda: _lib.call("pta_orf_basis", dv.ptr(locs_d), dv.ptr(zc_d), P, lmax, dv.ptr(basis), s))
+    tc = ev_time(lambda: _lib.call("pta_orf_combine", dv.ptr(basis), dv.ptr(clm), nb, P, dv.ptr(orf), s))
+    return {"n_psr": P, "lmax": lmax, "pairs": P * (P + 1) // 2, "modes": nb, "orf_basis_ms": tb, "orf_combine_ms": tc,
+            "host_pair_separations_ms": t_host * 1e3, "finite": bool(torch.isfinite(orf).all()),
+            "reference": "spharmORFbasis.correlated_basis: 12-15 min of Python for the same 20 100 pairs (BASELINE.md §2)"}
+
+
+def compact_line(full):
+    """the ONE JSON line of the contract, kept under ~6 KB: the driver's record keeps the flat keys of `roofline` / `cpu_baseline` and the
+    tail of the line, so every figure DESIGN.md quotes is a flat scalar here and the TD-mode ones come last; the complete record (nested
+    blocks, run lists, grid cells, API timing) goes to gpurun_out/bench_full.json and to stderr."""
+    def g(d, *path, default=None):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return default
+            d = d[k]
+        return d
+
+    def r(x, nd=4):
+        return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) else x
+
+    roof = full.get("roofline") or {}
+    td = full.get("td_mode") or {}
+    step = full.get("step") or {}
+    flat = {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "engine_clock_GHz")}
+    flat["traffic_source"] = "committed rocprofv3 PMC pass, keyed by kernel sources + launch shape" if roof.get("traffic") else None
+    flat["valu_insts_per_output_element"] = r(g(roof, "valu_issue", "insts_valu_per_output_element"), 1)
+    flat["valu_issue_frac_of_launch_at_measured_clock"] = r(g(roof, "valu_issue", "frac_of_launch_at_measured_clock"))
+    flat["step_frac_of_fp64_peak"] = r(step.get("frac_of_fp64_peak"))
+    flat["step_normals_T_per_s"] = r(step.get("normals_T_per_s"))
+    flat["gwb_stage_kernel"] = g(roof, "also", "kernel")
+    flat["gwb_stage_ms"] = r(g(roof, "also", "stage_ms"))
+    flat["gwb_stage_frac_of_fp64_peak"] = r(g(roof, "also", "frac"))
+    orf = full.get("orf_config5") or {}
+    flat["orf_basis_ms_P200_lmax4"] = r(orf.get("orf_basis_ms"))
+    flat["orf_combine_ms_P200_lmax4"] = r(orf.get("orf_combine_ms"))
+    flat["orf_host_pair_loop_ms_P200"] = r(orf.get("host_pair_separations_ms"), 1)
+    # TD mode (the north_star's dense path) on the SAME 68 x 5000 array, then the ragged arrays: flat scalars, fractions of 78.6 TFLOP/s / 8 TB/s
+    flat["td_cov_kernel"] = td.get("cov_assemble_kernel")
+    flat["td_cov_ms"] = r(td.get("cov_assemble_ms"))
+    flat["td_cov_TBps"] = r((td.get("cov_assemble_GBps_lower_triangle") or 0) / 1e3) if td.get("cov_assemble_GBps_lower_triangle") else None
+    flat["td_cov_frac_hbm"] = r((td.get("cov_assemble_GBps_lower_triangle") or 0) / HBM_PEAK_GBS) if td.get("cov_assemble_GBps_lower_triangle") else None
+    flat["td_cov_walk_ms"] = r(td.get("cov_assemble_walk_ms"))
+    flat["td_cov_tile_ms"] = r(td.get("cov_assemble_tile_ms"))
+    flat["td_potrf_ms"] = r(td.get("potrf_ms"))
+    flat["td_potrf_TFLOPs"] = r(td.get("potrf_TFLOPs"), 2)
+    flat["td_potrf_frac"] = r(td.get("potrf_frac_of_fp64_mfma_peak"))
+    flat["td_potrf_mfma_busy_pct_committed_pmc"] = r(td.get("potrf_trailing_update_mfma_busy_pct"), 1)
+    flat["td_trmm_ms_per_1024"] = r(td.get("generate_td_ms"))
+    flat["td_trmm_TFLOPs"] = r(td.get("trmm_useful_TFLOPs"), 2)
+    flat["td_trmm_frac"] = r(td.get("trmm_frac_of_fp64_mfma_peak"))
+    flat["td_realisations_per_s"] = r(td.get("realisations_per_s"), 1)
+    flat["td_prepare_first_call_ms"] = r(td.get("prepare_td_first_call_ms"), 1)
+    flat["td_prepare_warm_ms"] = r(td.get("prepare_td_ms"), 1)
+    flat["td_ragged_potrf_TFLOPs"] = r(g(td, "ragged", "potrf_TFLOPs"), 2)
+    flat["td_ragged_potrf_frac"] = r(g(td, "ragged", "potrf_frac_of_fp64_mfma_peak"))
+    flat["td_ragged_trmm_frac"] = r(g(td, "ragged", "trmm_frac_of_fp64_mfma_peak"))
+    flat["td_ragged_cov_TBps"] = r(g(td, "ragged", "cov_assemble_TBps"))
+    flat["td_config2_potrf_frac"] = r(g(td, "config2_shape", "potrf_frac_of_fp64_mfma_peak"))
+    flat["td_config2_realisations_per_s"] = r(g(td, "config2_shape", "realisations_per_s"), 1)
+    cb = full.get("cpu_baseline") or {}
+    cpu = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "value_without_ecorr", "host_cpus", "error") if k in cb}
+    if cb.get("sample"):
+        cpu["sample"] = cb["sample"][:160]
+    if g(cb, "reference_container", "value"):
+        cpu["unmodified_reference_in_build_container"] = g(cb, "reference_container", "value")
+    cfg = dict(full.get("config") or {})
+    if isinstance(cfg.get("workload"), str):
+        cfg["workload"] = cfg["workload"][:230]
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                     "dtype", "data")}
+    line["config"] = cfg
+    for k in ("value_fast_rng_math", "value_gwb_grid_draws", "value_single_deviate_wn", "api_mode_ms", "rccl_ranks_seen", "backend", "ms_per_step_per_rank"):
+        if k in full:
+            line[k] = r(full[k], 1) if isinstance(full[k], float) else full[k]
+    if isinstance(full.get("gathered_to_rank0"), dict):
+        line["gathered_to_rank0"] = {k: full["gathered_to_rank0"].get(k) for k in ("realisations", "ms", "realisations_per_s", "error") if k in full["gathered_to_rank0"]}
+    if isinstance(full.get("config4_shape"), dict):
+        line["config4_realisations_per_s"] = r(full["config4_shape"].get("realisations_per_s"), 1)
+    line["kernels_ms"] = full.get("kernels_ms")
+    if isinstance(full.get("gpu_over_cpu"), dict):
+        line["gpu_over_cpu"] = {k: r(v, 0) for k, v in full["gpu_over_cpu"].items()}
+    line["grid"] = [{"P": c.get("n_psr"), "N": c.get("n_toa"), "real_per_s": r(g(c, "throughput", "realisations_per_s"), 0),
+                     "td_potrf_frac": r(g(c, "td", "potrf_frac"), 3), "td_trmm_frac": r(g(c, "td", "trmm_frac"), 3)} for c in (full.get("grid") or []) if isinstance(c, dict)]
+    line["full_record"] = "gpurun_out/bench_full.json (+ stderr): td_mode, grid, step, engine_clocks, api_mode, cpu_baseline run lists, microbench"
+    line["cpu_baseline"] = cpu
+    line["roofline"] = {k: (r(v) if isinstance(v, float) else v) for k, v in flat.items()}
+    return line
 
 
 def main():
@@ -758,7 +892,7 @@ def main():
         def bail():
             if rank == 0:
                 line["gathered_to_rank0"] = {"error": "timed out after 60 s (watchdog)"}
-                print(json.dumps(line), flush=True)
+                print(json.dumps(compact_line(line)), flush=True)
             os._exit(0)
         dog = threading.Timer(60.0, bail)
         dog.daemon = True
@@ -987,7 +1121,20 @@ def main():
                 line["gpu_over_cpu"]["vs_reference_container_without_ecorr"] = line["value"] / rc_["value_without_ecorr"]
         except Exception as e:  # pragma: no cover
             line["cpu_baseline"] = {"error": str(e)[:400]}
-    print(json.dumps(line))
+    if world == 1 and not args.no_extras:
+        try:
+            line["orf_config5"] = orf_numbers()
+        except Exception as e:  # pragma: no cover
+            line["orf_config5"] = {"error": str(e)[:300]}
+    full_txt = json.dumps(line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as fh:
+            fh.write(full_txt + "\n")
+    except OSError:  # pragma: no cover
+        pass
+    print(full_txt, file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(line)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 6
+#define PTA_ABI_VERSION 7
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -390,6 +390,18 @@ int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *
                             const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                             const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,
                             void *stream);
+
+/* The same assembly by the COLUMN-WALKING kernel (ABI 7; 1 <= K <= 64, 64 ldf < 2^29): a wave keeps the phi-scaled operand of 64
+ * columns in registers and walks down the rows 16 at a time, every store instruction writes two whole 512-byte row segments; work
+ * items = (block, 256-column group, segment of 512 rows), exactly as many as the blocks' orders need - a ragged array launches no
+ * empty workgroups.  pta_td_cov_walk_items writes item0[b] = first item of block b (b <= n_blocks: item0[n_blocks] = the total,
+ * also returned; -1 on a bad argument) from the HOST copy of the orders; the caller keeps a device copy of item0 for the launch.
+ * Every k index is clamped to K - 1 before it forms an address: nothing behind the [K, ldf] design matrix is ever read.        */
+int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int32_t *item0_host);
+int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
+                             const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
+                             const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
+                             const int32_t *item0, int64_t n_items, void *stream);
 
 /* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or

@@ -107,6 +107,8 @@ def ra_dec(psr, default=None):
     neither DECJ nor ELAT: add_gwb silently leaves the pulsar at (0, 0) (red_noise.py:203-221: no else branch), which callers
     on that path request with default=(0.0, 0.0); add_cgw fails on it (deterministic.py:76-91), as this does without a default."""
     loc = psr.loc
+    if "DEC_RAD" in loc and "RA_RAD" in loc:   # simulate.from_enterprise: the radians an enterprise-style pulsar carried, unrounded
+        return float(loc["RA_RAD"]), float(loc["DEC_RAD"])
     if "DECJ" in loc:
         return float(loc["RAJ"] * np.pi / 12.0), float(loc["DECJ"] * np.pi / 180.0)
     if "ELAT" in loc:

@@ -21,33 +21,47 @@ rccl_api g_rccl;
 std::once_flag g_rccl_once;
 
 // the RCCL copy the process ALREADY uses (torch.distributed's, or the one a ctypes integrator loaded by full path), whatever its SONAME:
-// the loaded-object list is searched for "librccl" and that very file is re-opened (looking it up by the two usual names
-// could miss it and bind a second copy, whose ncclSend would then be handed the first copy's communicator)
-int rccl_find_loaded(struct dl_phdr_info *info, size_t, void *data) {
-  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
-    snprintf((char *)data, 1024, "%s", info->dlpi_name);
-    return 1;
-  }
-  return 0;
+// the loaded-object list is searched for a file whose BASENAME is librccl.so[.N...] and that very file is re-opened (looking
+// it up by the two usual names could miss it and bind a second copy, whose ncclSend would then be handed the first copy's communicator).
+// A network plugin (librccl-net.so, librccl_net_ofi.so, ...) also carries "librccl" in its name: the basename test rejects it,
+// and every candidate must export ncclSend before it is taken - the walk goes on otherwise.
+bool rccl_basename_matches(const char *path) {
+  const char *b = strrchr(path, '/');
+  b = b ? b + 1 : path;
+  if (strncmp(b, "librccl.so", 10) != 0) return false;
+  return b[10] == '\0' || b[10] == '.';
 }
 
-void rccl_load_once() {
-  rccl_api &r = g_rccl;
-  char path[1024] = {0};
-  void *h = nullptr;
-  if (dl_iterate_phdr(rccl_find_loaded, path) && path[0]) h = dlopen(path, RTLD_NOW | RTLD_NOLOAD);
-  if (!h)
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (h) break;
-    }
-  if (!h) return;
+bool rccl_bind(void *h, rccl_api &r) {
   r.send = (fn_sendrecv)dlsym(h, "ncclSend");
   r.recv = (fn_sendrecv)dlsym(h, "ncclRecv");
   r.gstart = (fn_group)dlsym(h, "ncclGroupStart");
   r.gend = (fn_group)dlsym(h, "ncclGroupEnd");
   r.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
-  r.ok = r.send && r.recv && r.gstart && r.gend;
+  return r.send && r.recv && r.gstart && r.gend;
+}
+
+int rccl_find_loaded(struct dl_phdr_info *info, size_t, void *data) {
+  if (!info->dlpi_name || !rccl_basename_matches(info->dlpi_name)) return 0;
+  void *h = dlopen(info->dlpi_name, RTLD_NOW | RTLD_NOLOAD);
+  if (h && rccl_bind(h, *(rccl_api *)data)) return 1;  // stop: bound
+  return 0;                                             // not a usable RCCL: keep walking
+}
+
+void rccl_load_once() {
+  rccl_api &r = g_rccl;
+  if (dl_iterate_phdr(rccl_find_loaded, &r)) {
+    r.ok = true;
+    return;
+  }
+  for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {  // nothing loaded yet: the usual names
+    void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (h && rccl_bind(h, r)) {
+      r.ok = true;
+      return;
+    }
+  }
+  r = rccl_api();
 }
 
 int rccl_load() {

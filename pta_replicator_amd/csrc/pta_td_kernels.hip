@@ -264,6 +264,221 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
   }
 }
 
+// ---- column-walking assembly (round 5) ---------------------------------------------------------------------------------------------
+// The tile kernel above is a short product (K = 60: four slabs) between a latency chain (block table -> operand rows -> LDS -> barrier)
+// and 64 KB of stores that must be acknowledged before the workgroup retires: per workgroup 3.4 us of matrix-pipe work in a 20 us
+// lifetime, three workgroups per CU -> 53 % MFMA-busy, 2.3 TB/s written.  Here a wave OWNS 64 columns of one pulsar's covariance for a
+// segment of TCW_SEG rows: its B operand - phi_k F[k, col], 4 column tiles x NKS k-steps - is loaded ONCE into registers (120 VGPRs at
+// K = 60) and stays there while the wave walks down the rows 16 at a time.  Per step: the A fragments of the NEXT step are requested
+// straight from the K-major design matrix (a lane's value F[4 ks + (l >> 4), row0 + (l & 15)]: four 128-byte row pieces per load, L1 /
+// L2 hits - a pulsar's F is 2.4 MB), 4 x NKS MFMAs, then the 16 x 64 result is turned through a WAVE-PRIVATE piece of LDS (no workgroup
+// barrier anywhere in the kernel: a wave's LDS operations execute in order) so that every store instruction writes two whole 512-byte
+// row segments, with the white / ECORR terms added on the way out.  Stores of step s drain under the products of steps s + 1, s + 2:
+// nothing waits for them until the wave retires, 32 steps later.
+//
+// Round 4's first column-walking kernel (32 columns per wave, 128-byte store pieces; commit ee73ef5, withdrawn in 18da960) "produced NaN
+// until a device-wide synchronisation" in one test sequence.  Cause (round 5; scripts/gpu_r5_nan_repro.py reproduces it on demand): for
+// K = 58 (components = 29: the failing case) its A-fragment loads of the cut k-step read rows k = 58, 59 of the [K, N] design matrix -
+// BEHIND its end - on the strength of "a masked k meets b = 0".  0 x finite = 0, but 0 x NaN = NaN: whenever the allocator had placed
+// a recycled NaN-poisoned block (the test's own d_Ltd.fill_(nan) clones) behind Ft, the accumulators turned NaN; any change of the
+// allocation history - a synchronisation with its frees included - moved finite bytes there and the symptom vanished.  No ordering
+// hazard was involved.  Here every k index is clamped to K - 1 (finite data) before it forms an address, and the tests run the kernel
+// on an Ft that is a view into a NaN-filled slab.
+#define TCW_COLS 64
+#define TCW_SEG 512
+#define TCW_SLD 80   // staging pitch (doubles) == 16 (mod 32): the two quarter-waves of a ds_write_b64 hit disjoint bank halves
+template <int NKS, bool EP>
+__global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
+                                                        const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
+                                                        const double *__restrict__ ecorr2, double *__restrict__ Cbase,
+                                                        const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
+                                                        const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off,
+                                                        const int32_t *__restrict__ item0, int n_blocks) {
+  __shared__ double __attribute__((aligned(16))) Sall[4][16][TCW_SLD];
+  __shared__ double __attribute__((aligned(16))) Rinfo[TCW_SEG][2];  // (ecorr2, sigma2) of the segment's rows
+  __shared__ double Repoch[TCW_SEG];                                 // their epochs (int32 -> double is exact)
+  // work item -> (pulsar, 256-column group, row segment); item0[b] = first item of pulsar b (host: pta_td_cov_walk_items)
+  int blk = 0;
+  {
+    int lo = 0, hi = n_blocks;  // largest blk with item0[blk] <= blockIdx.x
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (item0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+    }
+    blk = lo;
+  }
+  const int N = blk_n[blk];
+  int item = (int)blockIdx.x - item0[blk], cb = 0;
+  for (;; ++cb) {  // workgroup-uniform
+    const int ns = (N - 256 * cb + TCW_SEG - 1) / TCW_SEG;
+    if (item < ns) break;
+    item -= ns;
+    if (256 * (cb + 1) >= N) return;  // (cannot happen with a consistent item table)
+  }
+  const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = l & 15, lq = l >> 4;
+  const int c0 = 256 * cb + TCW_COLS * w;  // this wave's 64 columns
+  const int rbeg = 256 * cb + TCW_SEG * item, rend = min(N, rbeg + TCW_SEG);
+  const int64_t off = blk_off[blk];
+  // the white / ECORR terms of the segment's rows -> LDS, once per workgroup (its four waves walk the same rows): the kernel's ONLY
+  // workgroup barrier; the steps then issue nothing but fragment loads and stores
+#pragma unroll
+  for (int i = 0; i < TCW_SEG / 256; ++i) {
+    const int rr = t + 256 * i, row = min(rbeg + rr, N - 1);
+    Rinfo[rr][0] = EP ? ecorr2[off + row] : 0.0;
+    Rinfo[rr][1] = sigma2[off + row];
+    Repoch[rr] = EP ? (double)epoch_of[off + row] : -2.0;
+  }
+  __syncthreads();
+  if (c0 >= N) return;                      // no barrier below: a wave may leave alone
+  const int64_t ldc = blk_ld[blk];
+  double *__restrict__ C = Cbase + blk_pos[blk];
+  const double *__restrict__ F = Ft + off;
+  const double *__restrict__ ph = phi + (int64_t)blk * K;
+  double (*S)[TCW_SLD] = Sall[w];
+  // k rows of this lane: 4 ks + lq.  EVERY k is clamped to K - 1 BEFORE it forms an address (finite data meets b = 0; K <= 4 NKS, and a
+  // small K may leave whole k-steps past it).  A k-step that lies wholly inside K takes a wave-uniform base (SGPRs) + the lane's 32-bit
+  // element offset lq ldf + x (the host checks 64 ldf < 2^29): no 64-bit per-lane pointers in registers, one offset per step for all k-steps.
+  const uint32_t lqo = (uint32_t)lq * (uint32_t)ldf;
+  auto f_at = [&](int ks, uint32_t x) -> double {  // F[min(4 ks + lq, K - 1), x]
+    const bool whole = 4 * ks + 3 < K;             // kernel-uniform
+    const double *__restrict__ base = whole ? F + (int64_t)(4 * ks) * ldf : F;
+    const uint32_t o = whole ? lqo : (uint32_t)min(4 * ks + lq, K - 1) * (uint32_t)ldf;
+    return base[o + x];
+  };
+  // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, c0 + 16 jt + li]; k >= K enters as zero
+  double b[4][NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const double p = (4 * ks + lq < K) ? ph[min(4 * ks + lq, K - 1)] : 0.0;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) b[jt][ks] = p * f_at(ks, (uint32_t)min(c0 + 16 * jt + li, N - 1));
+  }
+  // store side: lane -> row (l >> 5) + 2 i of a step, columns c0 + 2 (l & 31), + 1
+  const int scol = c0 + 2 * (l & 31);
+  double ecA = -1.0, ecB = -1.0;  // epochs travel through the staging rows as doubles (int32 -> double is exact)
+  if (EP) {
+    ecA = scol < N ? (double)epoch_of[off + scol] : -1.0;
+    ecB = scol + 1 < N ? (double)epoch_of[off + scol + 1] : -1.0;
+  }
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  double a[NKS];
+  const int rfirst = max(rbeg, c0);  // rows above the wave's own columns are not in the lower triangle (both multiples of 16)
+  if (rfirst >= rend) return;
+  {
+    const uint32_t x = (uint32_t)min(rfirst + li, N - 1);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) a[ks] = f_at(ks, x);
+  }
+  auto step = [&](const int r0) {  // 16 rows x 64 columns; r0 wave-uniform
+    const bool diag_step = r0 < c0 + TCW_COLS;
+    const uint32_t xn = (uint32_t)min(r0 + 16 + li, N - 1);  // the next step's rows (past the segment: clamped, unused)
+    pta_f64x4 acc[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) acc[jt] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
+      a[ks] = f_at(ks, xn);               // the next step's fragment into the register just consumed
+      __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the fifteen loads behind the twelfth group of products)
+    }
+    // 16 x 64 result -> the wave's staging rows (acc[jt][reg] = element (lq + 4 reg, 16 jt + li))
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) S[lq + 4 * reg][16 * jt + li] = acc[jt][reg];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!diag_step && r0 + 16 <= N) {  // wave-uniform: strictly below the diagonal block, all 16 rows exist - nothing is predicated
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = (l >> 5) + 2 * i, row = r0 + rl;
+        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l & 31)]);
+        if (EP) {
+          const double e2 = Rinfo[row - rbeg][0], er = Repoch[row - rbeg];  // broadcast reads
+          v.x = er == ecA ? v.x + e2 : v.x;
+          v.y = er == ecB ? v.y + e2 : v.y;
+        }
+        *reinterpret_cast<f64x2 *>(C + (int64_t)row * ldc + scol) = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = (l >> 5) + 2 * i, row = r0 + rl;
+        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l & 31)]);
+        const f64x2 rt = *reinterpret_cast<const f64x2 *>(&Rinfo[min(row, rend - 1) - rbeg][0]);  // (ecorr2[row], sigma2[row])
+        const double er = Repoch[min(row, rend - 1) - rbeg];
+        if (er == ecA && scol <= row) v.x = v.x + rt.x;
+        if (er == ecB && scol + 1 <= row) v.y = v.y + rt.x;
+        if (scol == row) v.x = v.x + rt.y;
+        if (scol + 1 == row) v.y = v.y + rt.y;
+        double *__restrict__ dst = C + (int64_t)row * ldc + scol;
+        if (row < N) {
+          if (scol + 1 <= row)
+            *reinterpret_cast<f64x2 *>(dst) = v;
+          else if (scol == row)
+            dst[0] = v.x;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the next step's staging writes stay behind these reads
+  };
+  // first step peeled: inside the loop the wait in front of a group of products then counts the previous step's stores and the
+  // fragment loads behind it as YOUNGER operations (vmcnt(25)); merged with the kernel's prologue it would insist on vmcnt(14) and make
+  // every step wait for its predecessor's stores
+  step(rfirst);
+  for (int r0 = rfirst + 16; r0 < rend; r0 += 16) step(r0);
+}
+
+// number of work items of the column-walking kernel per block and in all: item0[b] = first item of block b, item0[n_blocks] = total
+extern "C" int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int32_t *item0_host) {
+  if (!blk_n_host || !item0_host || n_blocks <= 0) return -1;
+  int64_t tot = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    item0_host[b] = (int32_t)tot;
+    const int n = blk_n_host[b];
+    for (int cb = 0; 256 * cb < n; ++cb) tot += (n - 256 * cb + TCW_SEG - 1) / TCW_SEG;
+    if (tot >= (1LL << 31)) return -1;
+  }
+  item0_host[n_blocks] = (int32_t)tot;
+  return tot;
+}
+
+static int pta_td_cov_walk_nks(int K) { return K <= 0 || K > 64 ? 0 : (K > 56 && K <= 60 ? 15 : 4 * ((K + 15) / 16)); }
+
+extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
+                                        const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
+                                        const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
+                                        const int32_t *item0, int64_t n_items, void *stream) {
+  PTA_REQUIRE(Ft && phi && sigma2 && Cbase && blk_pos && blk_ld && blk_n && blk_off && item0, PTA_E_ARG, "pta_td_cov_assemble_walk: NULL argument");
+  PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble_walk: ecorr2 missing");
+  PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && n_items > 0 && n_items < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_walk: n_blocks=%d n_items=%lld",
+              n_blocks, (long long)n_items);
+  PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_walk: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
+  const int nks = pta_td_cov_walk_nks(K);
+  PTA_REQUIRE(nks > 0, PTA_E_ARG, "pta_td_cov_assemble_walk: needs 1 <= K <= 64 (K=%d): use pta_td_cov_assemble_all", K);
+  PTA_REQUIRE(ldf > 0 && 64 * ldf < (1LL << 29), PTA_E_ARG, "pta_td_cov_assemble_walk: ldf=%lld too large for 32-bit operand offsets", (long long)ldf);
+#define PTA_TCW_LAUNCH(NKSV)                                                                                                                \
+  if (epoch_of)                                                                                                                             \
+    hipLaunchKernelGGL((k_td_cov_walk<NKSV, true>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,     \
+                       epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks);                                         \
+  else                                                                                                                                      \
+    hipLaunchKernelGGL((k_td_cov_walk<NKSV, false>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,    \
+                       epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks)
+  switch (nks) {
+    case 4: PTA_TCW_LAUNCH(4); break;
+    case 8: PTA_TCW_LAUNCH(8); break;
+    case 12: PTA_TCW_LAUNCH(12); break;
+    case 15: PTA_TCW_LAUNCH(15); break;
+    default: PTA_TCW_LAUNCH(16); break;
+  }
+#undef PTA_TCW_LAUNCH
+  PTA_LAUNCH_CHECK();
+  return PTA_OK;
+}
+
 extern "C" int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                                        const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                                        const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks, int max_n,

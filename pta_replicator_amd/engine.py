@@ -41,7 +41,10 @@ def stream_id(kind, pulsar):
 
 class ReplicaEngine(TimeDomainMixin):
     def __init__(self, psrs, seed=0):
-        self.psrs = list(psrs)
+        # pulsars with the reference's SimulatedPulsar surface are used as they are; enterprise-style ones (toas [s] / toaerrs [s] /
+        # flags / pos as plain arrays: what simulate.py:91-95 hands on) are wrapped once through simulate.from_enterprise
+        from .simulate import as_simulated
+        self.psrs = [as_simulated(p) for p in psrs]
         self.P = len(self.psrs)
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.names = [p.name for p in self.psrs]

@@ -66,14 +66,12 @@ class TimeDomainMixin:
         # block layout arrays (also what the product kernel reads)
         self._td_layout = [dv.i64(pos[:-1]), dv.i32(ld), dv.i32(counts), dv.i32(self.off[:-1])]
         self._td_pad_idx = None
-        # one-off path: the host waits for the operands it has just computed (sigma2, the layout arrays) before the assembly is queued and
-        # for the assembly before the factorisation's internal streams are fed.  Stream order already guarantees both (measured:
-        # scripts/gpu_r4_stream_order.py); the two waits cost nothing next to a 57 ms factorisation and keep an unexplained observation
-        # of this round (a withdrawn assembly kernel produced NaN in one launch sequence until a device-wide
-        # synchronisation) from ever mattering here.  td_assemble() / td_factorise() themselves stay asynchronous.
-        torch.cuda.current_stream().synchronize()
+        # everything below is stream-ordered on the caller's stream: operands computed by torch, the assembly launch, the factorisation's
+        # internal chains (joined to the caller's stream through events).  Round 4 kept two host synchronisations here as insurance against
+        # an unexplained NaN observation; its cause was an out-of-range operand read of the withdrawn assembly kernel (DESIGN.md §4.2,
+        # csrc/pta_td_kernels.hip), not an ordering hazard, and tests/test_gpu_td.py::test_td_prepare_without_host_sync_* hold the
+        # asynchronous sequence bit-equal to a fully serialised one.
         self.td_assemble()
-        torch.cuda.current_stream().synchronize()
         self.td_factorise(lookahead=lookahead)
         blk, n0 = _strips(counts)
         self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0)]
@@ -95,16 +93,41 @@ class TimeDomainMixin:
         self._td_prepared = True
         return self
 
-    def td_assemble(self):
-        """ONE assembly launch over all pulsars: lower triangles of C_a into the factor buffer (+ the identity tail of odd orders)."""
+    def td_assemble(self, kernel=None):
+        """ONE assembly launch over all pulsars: lower triangles of C_a into the factor buffer (+ the identity tail of odd orders).
+        kernel (default: attribute td_cov_kernel, "auto"): "walk" = the column-walking kernel (pta_td_cov_assemble_walk: 1 <= K <= 64,
+        work items sized by every pulsar's own order), "tile" = the 64 x 128-tile kernel (pta_td_cov_assemble_all: any K, grid sized by
+        the largest pulsar), "auto" = walk where it applies."""
         pl, P, N, s = self.plan, self.P, self.n_toa, dv.stream_ptr()
         counts = [int(c) for c in self.counts]
         K = pl.rn_k
         phi = (self.d_amp ** 2).contiguous() if K else None
         ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if pl.ecorr_toa else None
-        _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
-                  dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
-                  dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
+        kernel = kernel or getattr(self, "td_cov_kernel", "auto")
+        walk_ok = 1 <= K <= 64 and 64 * N < (1 << 29)
+        if kernel == "auto":
+            kernel = "walk" if walk_ok else "tile"
+        if kernel == "walk":
+            if not walk_ok:
+                raise ValueError(f"td_cov_kernel='walk' needs 1 <= K <= 64 red-noise columns and 64 n_toa < 2^29 (K={K}, n_toa={N})")
+            items = getattr(self, "_td_walk_items", None)
+            if items is None or items[0] != tuple(counts):
+                h_n = np.ascontiguousarray(counts, dtype=np.int32)
+                item0 = np.zeros(P + 1, dtype=np.int32)
+                total = int(_lib.lib.pta_td_cov_walk_items(dv.hptr(h_n), P, dv.hptr(item0)))
+                if total <= 0:
+                    raise _lib.PtaError("pta_td_cov_walk_items failed")
+                items = self._td_walk_items = (tuple(counts), dv.i32(item0), total)
+            _lib.call("pta_td_cov_assemble_walk", dv.ptr(self.d_Ft), N, K, dv.ptr(phi), dv.ptr(self._td_sigma2),
+                      dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
+                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, dv.ptr(items[1]), items[2], s)
+        elif kernel == "tile":
+            _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
+                      dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
+                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, max(counts), s)
+        else:
+            raise ValueError(f"td_cov_kernel={kernel!r}: 'auto', 'walk' or 'tile'")
+        self.td_cov_kernel_used = kernel
         pad = getattr(self, "_td_pad_idx", None)
         if pad is None:   # the identity row of every odd order: positions of its zeros and of its one, built once per layout
             rows, ones = [], []
@@ -131,6 +154,16 @@ class TimeDomainMixin:
         info = dv.zeros((P,), dtype=torch.int32)
         extra = int(getattr(self, "td_potrf_flags", 0))
         if mode == "ragged":
+            # the ragged schedule always runs the workspace scheme (P x NBO^2 doubles for the factorisation only: 8.4 MB per pulsar at
+            # 1024-column panels, 33.5 MB at the 2048 columns the plan takes for arrays of large matrices) with its own look-ahead:
+            # options that only the uniform path honours are refused instead of being ignored
+            if not bool(getattr(self, "td_potrf_workspace", True)):
+                raise ValueError("td_potrf_workspace = False is a uniform-batch option: the ragged schedule (pulsars of different TOA counts) needs its "
+                                 "workspace; use td_potrf_mode = 'uniform' for the workspace-free per-matrix schedule")
+            bad = extra & (_lib.POTRF_DIAG_AHEAD | _lib.POTRF_LOCKSTEP)
+            if bad:
+                raise ValueError(f"td_potrf_flags 0x{bad:x} (PTA_POTRF_DIAG_AHEAD / PTA_POTRF_LOCKSTEP) are uniform-batch options: the ragged schedule "
+                                 "has its own look-ahead (PTA_POTRF_NO_LOOKAHEAD turns it off)")
             flags = (0 if lookahead else _lib.POTRF_NO_LOOKAHEAD) | extra
             key = (tuple(nst), flags)
             if getattr(self, "_td_rag_key", None) != key:

@@ -132,6 +132,66 @@ class ArrayTOAs:
         self.shift_day = np.zeros(len(self.mjd_ld), dtype=np.float64)
 
 
+class EnterpriseTOAs(ArrayTOAs):
+    """ArrayTOAs over the arrays of an enterprise-style pulsar (``toas`` [s], ``toaerrs`` [s]): the MJD column is toas / 86400 in
+    longdouble and the uncertainties stay in SECONDS, so ``get_errors().to('s')`` - what the injection functions and the engine read
+    (white_noise.py:105) - hands back the caller's numbers bit for bit instead of a us round trip."""
+
+    def __init__(self, toas_s, toaerrs_s, flags=None, freqs_mhz=1440.0):
+        toas_s = np.asarray(toas_s, dtype=np.float64)
+        super().__init__(toas_s.astype(np.longdouble) / np.longdouble(86400.0), np.asarray(toaerrs_s, dtype=np.float64) * 1e6, flags, freqs_mhz)
+        self.errors_s = np.array(toaerrs_s, dtype=np.float64) * np.ones(len(toas_s))
+
+    def get_errors(self):
+        return self.errors_s.copy() * u.s
+
+
+def is_enterprise_like(psr):
+    """an object with enterprise.pulsar.BasePulsar's array surface (``toas`` [s] and ``toaerrs`` [s] as plain arrays) rather than the
+    reference's SimulatedPulsar surface (``toas.get_mjds()`` ...)"""
+    toas = getattr(psr, "toas", None)
+    return toas is not None and not hasattr(toas, "get_mjds") and hasattr(psr, "toaerrs") and np.ndim(toas) == 1
+
+
+def from_enterprise(epsr):
+    """Array-backed ``SimulatedPulsar`` from an ENTERPRISE-style pulsar - the objects BASELINE.json's north_star names and the
+    reference's hand-off produces (simulate.py:91-95).  Read, in enterprise's units (enterprise/pulsar.py): ``name``; ``toas`` [s] =
+    MJD * 86400; ``toaerrs`` [s]; ``freqs`` [MHz] (optional); ``flags`` (dict flag -> per-TOA array; '' = the TOA lacks the flag) and
+    ``backend_flags`` (becomes flag ``f`` when ``flags`` has none); position from ``_raj`` / ``_decj`` [rad] when present (enterprise keeps
+    them), else ``phi`` / ``theta``, else the unit vector ``pos``.  The result is ``make_ideal``-ed: every ``add_*`` function and
+    ``ReplicaEngine`` take it as is (the engine also accepts the enterprise-style objects directly and wraps them through this).
+    Nothing is written back into ``epsr``: hand realisations back with ``SimulatedPulsar.to_enterprise()`` /
+    ``ReplicaEngine.to_enterprise()``."""
+    toas_s = np.asarray(epsr.toas, dtype=np.float64)
+    n = len(toas_s)
+    toaerrs = np.asarray(epsr.toaerrs, dtype=np.float64) * np.ones(n)
+    freqs = np.asarray(getattr(epsr, "freqs", 1440.0), dtype=np.float64) * np.ones(n)
+    fl = getattr(epsr, "flags", None) or {}
+    cols = {str(k): np.asarray(v) for k, v in dict(fl).items() if np.ndim(v) == 1 and len(v) == n}
+    if "f" not in cols and getattr(epsr, "backend_flags", None) is not None and len(epsr.backend_flags) == n:
+        cols["f"] = np.asarray(epsr.backend_flags)
+    flags = [{k: str(v[i]) for k, v in cols.items() if str(v[i]) != ""} for i in range(n)]
+    if getattr(epsr, "_raj", None) is not None and getattr(epsr, "_decj", None) is not None:
+        ra, dec = float(epsr._raj), float(epsr._decj)
+    elif getattr(epsr, "phi", None) is not None and getattr(epsr, "theta", None) is not None:
+        ra, dec = float(epsr.phi), float(np.pi / 2 - epsr.theta)
+    elif getattr(epsr, "pos", None) is not None:
+        x, y, z = (float(c) for c in np.asarray(epsr.pos, dtype=np.float64)[:3])
+        ra, dec = float(np.arctan2(y, x) % (2 * np.pi)), float(np.arcsin(max(-1.0, min(1.0, z / np.sqrt(x * x + y * y + z * z)))))
+    else:
+        raise AttributeError(f"enterprise-style pulsar {getattr(epsr, 'name', '?')}: no position (_raj/_decj, phi/theta or pos)")
+    # RAJ [hourangle] / DECJ [deg] as the reference's loc dict holds them; RA_RAD / DEC_RAD carry the radians unrounded (_position.ra_dec)
+    loc = {"RAJ": ra * 12.0 / np.pi, "DECJ": np.degrees(dec), "RA_RAD": ra, "DEC_RAD": dec}
+    psr = SimulatedPulsar(toas=EnterpriseTOAs(toas_s, toaerrs, flags, freqs), name=str(epsr.name), loc=loc)
+    make_ideal(psr)
+    return psr
+
+
+def as_simulated(psr):
+    """``psr`` itself when it has the reference's SimulatedPulsar surface, else (enterprise-style arrays) its from_enterprise() wrapper"""
+    return from_enterprise(psr) if is_enterprise_like(psr) else psr
+
+
 @dataclass
 class SimulatedPulsar:
     """Same fields and methods as the reference's dataclass (simulate.py:23-95)."""
@@ -262,6 +322,7 @@ class ArrayEnterprisePulsar:
         else:
             self.backend_flags = np.array([""] * len(order))
         self.Mmat, self.fitpars = timing_design_matrix(self.toas, ra, dec, timing_model)
+        self._raj, self._decj = float(ra), float(dec)   # enterprise keeps the radians it derived pos / theta / phi from
         self.theta, self.phi = float(np.pi / 2 - dec), float(ra)
         self.pos = np.array([np.cos(ra) * np.cos(dec), np.sin(ra) * np.cos(dec), np.sin(dec)])
         self.pdist = (1.0, 0.2)

@@ -102,17 +102,29 @@ def _per_flag_vector(labels, codes, flags, values):
 
 def errors_seconds(toas):
     """TOA uncertainties in seconds as float64 (white_noise.py:105: ``get_errors().to('s')``), converted once per TOA object - the
-    errors are injection-invariant - and cached on it (keyed by the TOA count)."""
+    errors are injection-invariant - and cached on it.  The cache is validated by CONTENT, never by object identity alone: array-backed
+    TOAs are checked against their source column (``errors_us``), any other container (PINT-style: ``get_errors()`` returns a fresh
+    Quantity on every call) against the raw values of ``get_errors()`` itself - a comparison of N doubles instead of a unit conversion
+    through astropy (the round-4 revision cached only the array-backed kind)."""
     src = getattr(toas, "errors_us", None)      # array-backed TOAs: the source column itself (no unit conversion needed to validate)
     hit = getattr(toas, "_pta_errors_s", None)
-    if src is not None and hit is not None and hit[0] is src and len(hit[2]) == len(src) and np.array_equal(hit[1], src):
-        return hit[2]                            # same column object, same content (ADVICE r3: a rescaled error column must not be served stale)
-    sig = np.asarray(toas.get_errors().to("s").value, dtype=np.float64)
     if src is not None:
-        try:
-            toas._pta_errors_s = (src, np.array(src, copy=True), sig)
-        except AttributeError:
-            pass
+        if hit is not None and hit[0] is src and len(hit[2]) == len(src) and np.array_equal(hit[1], src):
+            return hit[2]                        # same column object, same content (ADVICE r3: a rescaled error column must not be served stale)
+        sig = np.asarray(toas.get_errors().to("s").value, dtype=np.float64)
+        key = (src, np.array(src, copy=True), sig)
+    else:
+        q = toas.get_errors()
+        raw = np.asarray(getattr(q, "value", q), dtype=np.float64)
+        unit = str(getattr(q, "unit", ""))
+        if hit is not None and hit[0] == unit and hit[1].shape == raw.shape and np.array_equal(hit[1], raw):
+            return hit[2]
+        sig = np.asarray(q.to("s").value, dtype=np.float64)
+        key = (unit, np.array(raw, copy=True), sig)
+    try:
+        toas._pta_errors_s = key
+    except AttributeError:
+        pass
     return sig
 
 

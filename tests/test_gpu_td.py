@@ -388,3 +388,128 @@ def test_td_draws_from_memory_equal_draws_in_registers():
     assert torch.equal(eng.generate_td(70, r0=5), ref)
     eng.td_fill_beside_gwb = True         # opt-in: the deviate fill on a second stream beside the GWB grid stage
     assert torch.equal(eng.generate_td(70, r0=5), ref)
+
+
+def _ragged_engine(components, sizes=(777, 90, 1025, 2601), jitter=True, seed=None, toas_per_epoch=3):
+    """a small ragged array: odd counts, a count below one 256-column group, multi-TOA ECORR epochs, a pulsar without red noise"""
+    from pta_replicator_amd.engine import ReplicaEngine
+    from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+    rng = np.random.default_rng(components if seed is None else seed)
+    psrs = []
+    for a, n in enumerate(sizes):
+        ep = np.sort(rng.uniform(53000, 56000, n // toas_per_epoch + 1))
+        mjd = (ep[:, None] + rng.uniform(0, 0.01, (len(ep), toas_per_epoch))).ravel()[:n]
+        p = SimulatedPulsar(toas=ArrayTOAs(mjd, rng.uniform(0.3, 1.5, n)), name=f"J{a:04d}", loc={"RAJ": 2.0 + 3 * a, "DECJ": -20.0 + 25 * a})
+        make_ideal(p)
+        psrs.append(p)
+    eng = ReplicaEngine(psrs, seed=3)
+    eng.set_white_noise(efac=1.1, log10_equad=-6.3)
+    if jitter:
+        eng.set_jitter(log10_ecorr=-6.5, coarsegrain=0.1)
+    P = len(sizes)
+    eng.set_red_noise([None if a == 1 else -13.6 - 0.2 * a for a in range(P)], [None if a == 1 else 3.1 + 0.4 * (a % 3) for a in range(P)], components=components)
+    return eng.prepare()
+
+
+@pytest.mark.parametrize("components,jitter", [(30, True), (32, True), (29, True), (29, False), (10, True), (2, True), (13, False)])
+def test_td_covariance_walk_kernel_equals_the_tile_kernel_inside_a_nan_slab(components, jitter):
+    """pta_td_cov_assemble_walk (a wave keeps the phi-scaled operand of its 64 columns in registers and walks down the rows) against
+    pta_td_cov_assemble_all (64 x 128 tiles through LDS), K = 60 / 64 / 58 / 20 / 4 / 26: whole, cut and missing k-steps, with and without
+    ECORR.  The design matrix is a VIEW into a slab that is NaN in front of and behind it - round 4's withdrawn kernel read rows k >= K behind
+    the matrix and multiplied them by zero (0 x NaN = NaN: scripts/gpu_r5_nan_repro.py); any such read shows up here.  The lower
+    triangles agree to rounding (phi enters on the other operand) and nothing outside them is written."""
+    import torch
+    eng = _ragged_engine(components, jitter=jitter)
+    K, N = eng.plan.rn_k, eng.n_toa
+    slab = torch.full((4 * N + K * N + 4 * N,), float("nan"), dtype=torch.float64, device="cuda")
+    slab[4 * N:4 * N + K * N] = eng.d_Ft.reshape(-1)
+    eng.d_Ft = slab[4 * N:4 * N + K * N].view(K, N)
+    eng.prepare_td()
+    assert eng.td_cov_kernel_used == "walk"
+    got = {}
+    for kernel in ("tile", "walk"):
+        eng.d_Ltd.fill_(float("nan"))
+        eng.td_assemble(kernel=kernel)
+        got[kernel] = eng.d_Ltd.clone()
+    for a in range(eng.P):
+        n, ld, pos = int(eng.counts[a]), eng.td_ld[a], int(eng.td_pos[a])
+        v1 = got["tile"][pos:pos + n * ld].view(n, ld)[:, :n].cpu().numpy()
+        v2 = got["walk"][pos:pos + n * ld].view(n, ld)[:, :n].cpu().numpy()
+        lo = np.tril_indices(n)
+        assert np.all(np.isfinite(v2[lo])), a
+        assert np.max(np.abs(v1[lo] - v2[lo])) < 1e-13 * np.max(np.abs(v1[lo])), a
+        up = np.triu_indices(n, 1)
+        assert np.all(np.isnan(v2[up])), a                                             # the upper triangle is not touched
+        pad = got["walk"][pos:pos + n * ld].view(n, ld)[:, n:].cpu().numpy()
+        assert np.all(np.isnan(pad)), a                                                # nor the row padding
+    out = eng.generate_td(3)                                                          # and the factorisation is happy with it
+    assert bool(torch.isfinite(out).all())
+
+
+def _poison_allocator(torch, sizes_mb=(1, 3, 17, 64, 200, 700)):
+    """leave NaN-filled blocks of assorted sizes in the caching allocator's pools: whatever is allocated next (factor buffers, potrf
+    workspaces, operand temporaries) starts out as NaN, so a kernel that consumes bytes it did not produce cannot go unnoticed"""
+    blocks = [torch.full((mb * (1 << 20) // 8,), float("nan"), dtype=torch.float64, device="cuda") for mb in sizes_mb for _ in range(2)]
+    del blocks
+
+
+def _lower_factors(eng, torch):
+    return [torch.tril(eng.d_Ltd[int(eng.td_pos[a]):int(eng.td_pos[a]) + eng.td_nst[a] * eng.td_ld[a]].view(eng.td_nst[a], eng.td_ld[a])[:, :eng.td_nst[a]]).clone()
+            for a in range(eng.P)]
+
+
+def _prepare_td_serialised(eng, torch):
+    """prepare_td() with a device-wide synchronisation around every stage (the reference of the stress test below)"""
+    torch.cuda.synchronize()
+    eng.d_Ltd.fill_(float("nan"))
+    torch.cuda.synchronize()
+    eng.td_assemble()
+    torch.cuda.synchronize()
+    eng.td_factorise()
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("kernel", ["walk", "tile"])
+def test_td_prepare_without_host_sync_is_bit_equal_to_a_serialised_run(kernel):
+    """three engines back to back in one process - a uniform batch, a ragged array and BASELINE config 2's shape (three orders,
+    two of them odd; here at a tenth of the TOA counts so that 20 repetitions fit the test budget, the full shape runs in the next test) -
+    with the allocator's free blocks poisoned with NaN before every prepare_td(), no host synchronisation between td_assemble() and
+    td_factorise() (the product path has none since round 5), 20 repetitions: every factor bit-equal to the one a fully serialised run
+    (device-wide synchronisation around every stage) produced."""
+    import torch
+    engines = [_ragged_engine(30, sizes=(1000,) * 6, seed=11), _ragged_engine(30, seed=12), _ragged_engine(30, sizes=(776, 2303, 3503), seed=13)]
+    refs = []
+    for eng in engines:
+        eng.td_cov_kernel = kernel
+        eng.prepare_td()
+        _prepare_td_serialised(eng, torch)
+        refs.append(_lower_factors(eng, torch))
+    for rep in range(20):
+        for eng, ref in zip(engines, refs):
+            eng.d_Ltd = None                                                            # the factor buffer's block goes back to the pool ...
+            _poison_allocator(torch)                                                    # ... and is poisoned with the rest
+            eng.prepare_td()                                                            # fresh factor buffer and workspaces out of the poisoned pools
+            for a, (got, want) in enumerate(zip(_lower_factors(eng, torch), ref)):
+                assert torch.equal(got, want), (rep, eng.P, a)
+
+
+def test_td_prepare_without_host_sync_config2_shape():
+    """the same at BASELINE config 2's full TOA counts (7758 / 23 023 / 35 037: 14.6 GB of factors, one ragged schedule), 3 repetitions"""
+    import torch
+    if torch.cuda.get_device_properties(0).total_memory < 100e9:
+        pytest.skip("needs ~45 GB of device memory")
+    eng = _ragged_engine(30, sizes=(7758, 23023, 35037), seed=14, toas_per_epoch=4)
+    eng.prepare_td()
+    _prepare_td_serialised(eng, torch)
+    ref = _lower_factors(eng, torch)
+    for rep in range(3):
+        eng.d_Ltd = None
+        _poison_allocator(torch, sizes_mb=(1, 64, 700, 4000, 15000))
+        eng.prepare_td()
+        for a, want in enumerate(ref):
+            n, ld, pos = eng.td_nst[a], eng.td_ld[a], int(eng.td_pos[a])
+            got = torch.tril(eng.d_Ltd[pos:pos + n * ld].view(n, ld)[:, :n])
+            assert torch.equal(got, want), (rep, a)
+            del got
+    out = eng.generate_td(2)
+    assert bool(torch.isfinite(out).all())
