@@ -188,6 +188,11 @@ int64_t pta_potrf_workspace_doubles(int n, int B, int flags);
 int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
                          int64_t work_doubles, void *stream);
 
+/* Creates the internal streams / events the chained schedules of pta_potrf_batched_ws / pta_potrf_ragged use (per calling thread and
+ * device; nchain <= 0: the default two chains + their look-ahead streams) NOW instead of inside the first factorisation - a HIP stream
+ * is a hardware queue, ~10 ms each to create (ABI 7; profiles/r05_prepare_td_first_call.txt).  Optional: the schedules create on demand. */
+int pta_potrf_warmup(int nchain);
+
 /* RAGGED batch (ABI 6): B matrices of DIFFERENT orders factored as ONE schedule - the shape of a real pulsar timing array (the
  * reference's noise_dicts/ng15_dict.json: 68 pulsars, 68 TOA counts; test_partim: 7758 / 23023 / 35037 TOAs), which the reference
  * handles by looping over pulsars (red_noise.py:286-298) and a batch-by-equal-order scheme would run as B batches of one.

@@ -326,7 +326,8 @@ __global__ void k_zero_upper(double *__restrict__ A, int n, int64_t lda, int64_t
 #define PTA_POTRF_MAX_CHAINS 4
 #define PTA_POTRF_MAX_DEVICES 16
 struct pta_potrf_ctx {
-  bool ready = false;
+  bool base = false;                    // ev_in exists
+  bool made[PTA_POTRF_MAX_CHAINS] = {false, false, false, false};  // streams and events of chain i exist
   hipStream_t chain[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_in = nullptr, ev_out[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_diag[PTA_POTRF_MAX_CHAINS] = {nullptr, nullptr, nullptr, nullptr};  // chain c's first diagonal phase is done
@@ -336,25 +337,36 @@ struct pta_potrf_ctx {
 };
 static thread_local pta_potrf_ctx g_potrf_ctx[PTA_POTRF_MAX_DEVICES];
 
-static int pta_potrf_ctx_get(pta_potrf_ctx **out) {
+// the context of (calling thread, current device) with the streams / events of chains 0 .. nchain - 1 in place.  Created ON DEMAND, chain
+// by chain: a HIP stream is a hardware queue (~10 ms each to create on this stack - profiles/r05_prepare_td_first_call.txt), the default
+// schedule uses two chains + their two look-ahead streams, and round 4 created all eight at the first call whatever it needed.
+static int pta_potrf_ctx_get(pta_potrf_ctx **out, int nchain = PTA_POTRF_MAX_CHAINS) {
   int dev = 0;
   PTA_HIP(hipGetDevice(&dev));
   PTA_REQUIRE(dev >= 0 && dev < PTA_POTRF_MAX_DEVICES, PTA_E_ARG, "pta_potrf_batched: device ordinal %d beyond %d", dev, PTA_POTRF_MAX_DEVICES);
   pta_potrf_ctx &c = g_potrf_ctx[dev];
-  if (!c.ready) {
-    for (int i = 0; i < PTA_POTRF_MAX_CHAINS; ++i) {
-      PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
-      PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
-      PTA_HIP(hipEventCreateWithFlags(&c.ev_diag[i], hipEventDisableTiming));
-      PTA_HIP(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
-      PTA_HIP(hipEventCreateWithFlags(&c.ev_u1[i], hipEventDisableTiming));
-      PTA_HIP(hipEventCreateWithFlags(&c.ev_la[i], hipEventDisableTiming));
-    }
+  if (!c.base) {
     PTA_HIP(hipEventCreateWithFlags(&c.ev_in, hipEventDisableTiming));
-    c.ready = true;
+    c.base = true;
+  }
+  for (int i = 0; i < nchain && i < PTA_POTRF_MAX_CHAINS; ++i) {
+    if (c.made[i]) continue;
+    PTA_HIP(hipStreamCreateWithFlags(&c.chain[i], hipStreamNonBlocking));
+    PTA_HIP(hipEventCreateWithFlags(&c.ev_out[i], hipEventDisableTiming));
+    PTA_HIP(hipEventCreateWithFlags(&c.ev_diag[i], hipEventDisableTiming));
+    PTA_HIP(hipStreamCreateWithFlags(&c.side[i], hipStreamNonBlocking));
+    PTA_HIP(hipEventCreateWithFlags(&c.ev_u1[i], hipEventDisableTiming));
+    PTA_HIP(hipEventCreateWithFlags(&c.ev_la[i], hipEventDisableTiming));
+    c.made[i] = true;
   }
   *out = &c;
   return PTA_OK;
+}
+
+// creates the internal streams / events of the factorisation's default schedule now instead of inside the first factorisation (ABI 7)
+extern "C" int pta_potrf_warmup(int nchain) {
+  pta_potrf_ctx *cx = nullptr;
+  return pta_potrf_ctx_get(&cx, nchain <= 0 ? 2 : (nchain > PTA_POTRF_MAX_CHAINS ? PTA_POTRF_MAX_CHAINS : nchain));
 }
 
 // Factor columns [c0, c0 + w) of every matrix of the batch for ALL rows below them, all updates from columns < c0 already
@@ -1014,7 +1026,7 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   if (use_ws && (flags & PTA_POTRF_DIAG_AHEAD) && !(flags & PTA_POTRF_NO_LOOKAHEAD)) {
     pta_potrf_ctx *cx = nullptr;
-    int rc = pta_potrf_ctx_get(&cx);
+    int rc = pta_potrf_ctx_get(&cx, nchain);
     if (rc != PTA_OK) return rc;
     PTA_HIP(hipEventRecord(cx->ev_in, s));
     int rc_chain = PTA_OK;
@@ -1038,7 +1050,7 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
     }
   } else {
     pta_potrf_ctx *cx = nullptr;
-    int rc = pta_potrf_ctx_get(&cx);
+    int rc = pta_potrf_ctx_get(&cx, nchain);
     if (rc != PTA_OK) return rc;
     PTA_HIP(hipEventRecord(cx->ev_in, s));
     // the launches are ENQUEUED panel step by panel step across the chains (a chain's ~235 launches take the host longer than
@@ -1302,7 +1314,7 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
   hipStream_t s = pta_stream(stream);
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   pta_potrf_ctx *cx = nullptr;
-  int rc = pta_potrf_ctx_get(&cx);
+  int rc = pta_potrf_ctx_get(&cx, nchain);
   if (rc != PTA_OK) return rc;
   const bool la = !(flags & PTA_POTRF_NO_LOOKAHEAD);
   if (nchain > 1 || la) PTA_HIP(hipEventRecord(cx->ev_in, s));

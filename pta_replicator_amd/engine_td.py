@@ -59,8 +59,10 @@ class TimeDomainMixin:
         ld = [(n + 15) // 16 * 16 for n in nst]           # rows start on 128-byte lines (and even: the product kernel loads double2)
         pos = np.concatenate([[0], np.cumsum([n * l for n, l in zip(nst, ld)])]).astype(np.int64)
         self.td_ld, self.td_pos, self.td_nst = ld, pos, nst
-        self.d_Ltd = None                                  # release a previous factor buffer first: two do not fit at SKA scale
-        self.d_Ltd = dv.empty((int(pos[-1]),))
+        cur = getattr(self, "d_Ltd", None)
+        if cur is None or cur.numel() != int(pos[-1]):     # a buffer of the right size is factored in again (first-touch paid once)
+            self.d_Ltd = None                              # release a previous factor buffer first: two do not fit at SKA scale
+            self.d_Ltd = dv.empty((int(pos[-1]),))
         sigma2 = self.d_wn_a ** 2 + self.d_wn_b ** 2      # (efac sigma)^2 + (efac equad | equad)^2
         self._td_sigma2 = sigma2
         # block layout arrays (also what the product kernel reads)
