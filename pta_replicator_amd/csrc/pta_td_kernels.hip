@@ -284,20 +284,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // allocation history - a synchronisation with its frees included - moved finite bytes there and the symptom vanished.  No ordering
 // hazard was involved.  Here every k index is clamped to K - 1 (finite data) before it forms an address, and the tests run the kernel
 // on an Ft that is a view into a NaN-filled slab.
-#define TCW_COLS 64
 #define TCW_SEG 512
-#define TCW_SLD 80   // staging pitch (doubles) == 16 (mod 32): the two quarter-waves of a ds_write_b64 hit disjoint bank halves
-template <int NKS, bool EP>
-__global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
+// NT = 16-column tiles a wave owns (4: 64 columns, two workgroups per CU, 226-240 VGPRs; 8: 128 columns, ONE workgroup per CU with the
+// whole 512-entry register file per wave - 1 KB row segments per store, half the fragment traffic per byte written).  DIST = how many
+// steps ahead the A fragments are requested (a ring of DIST register sets, each set reloading itself for the step DIST ahead as its
+// values are consumed).  Why DIST matters beyond latency: on gfx950 loads and stores share ONE counter (vmcnt) and complete out of
+// order with respect to each other, so the wait in front of a group of products can only be "at most as many operations outstanding as
+// there are YOUNGER LOADS" (15 DIST - 1) - outstanding stores count against that allowance.  With DIST = 1 about 9 of the 14 younger
+// loads are still in flight (an L2 hit takes ~9 groups of products), which leaves room for ~5 outstanding 1 KB stores per wave - 10 MB
+// over the chip, Little's law for ~3 TB/s at the ~3 us a store takes to be acknowledged under load: the 2.96 TB/s measured.  DIST = 2
+// triples the allowance.
+template <int NKS, bool EP, int NT, int DIST>
+__global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
                                                         const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
                                                         const double *__restrict__ ecorr2, double *__restrict__ Cbase,
                                                         const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
                                                         const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off,
                                                         const int32_t *__restrict__ item0, int n_blocks) {
-  __shared__ double __attribute__((aligned(16))) Sall[4][16][TCW_SLD];
+  constexpr int COLS = 16 * NT;        // columns per wave
+  constexpr int WGC = 4 * COLS;        // columns per workgroup
+  constexpr int SLD = COLS + 16;       // staging pitch (doubles) == 16 (mod 32): the two quarter-waves of a ds_write_b64 hit disjoint bank halves
+  constexpr int LPR = COLS / 2;        // lanes per stored row (two columns each)
+  constexpr int RPI = 64 / LPR;        // rows per store instruction
+  __shared__ double __attribute__((aligned(16))) Sall[4][16][SLD];
   __shared__ double __attribute__((aligned(16))) Rinfo[TCW_SEG][2];  // (ecorr2, sigma2) of the segment's rows
   __shared__ double Repoch[TCW_SEG];                                 // their epochs (int32 -> double is exact)
-  // work item -> (pulsar, 256-column group, row segment); item0[b] = first item of pulsar b (host: pta_td_cov_walk_items)
+  // work item -> (pulsar, WGC-column group, row segment); item0[b] = first item of pulsar b (host: pta_td_cov_walk_items)
   int blk = 0;
   {
     int lo = 0, hi = n_blocks;  // largest blk with item0[blk] <= blockIdx.x
@@ -310,14 +322,14 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
   const int N = blk_n[blk];
   int item = (int)blockIdx.x - item0[blk], cb = 0;
   for (;; ++cb) {  // workgroup-uniform
-    const int ns = (N - 256 * cb + TCW_SEG - 1) / TCW_SEG;
+    const int ns = (N - WGC * cb + TCW_SEG - 1) / TCW_SEG;
     if (item < ns) break;
     item -= ns;
-    if (256 * (cb + 1) >= N) return;  // (cannot happen with a consistent item table)
+    if (WGC * (cb + 1) >= N) return;  // (cannot happen with a consistent item table)
   }
   const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = l & 15, lq = l >> 4;
-  const int c0 = 256 * cb + TCW_COLS * w;  // this wave's 64 columns
-  const int rbeg = 256 * cb + TCW_SEG * item, rend = min(N, rbeg + TCW_SEG);
+  const int c0 = WGC * cb + COLS * w;  // this wave's columns
+  const int rbeg = WGC * cb + TCW_SEG * item, rend = min(N, rbeg + TCW_SEG);
   const int64_t off = blk_off[blk];
   // the white / ECORR terms of the segment's rows -> LDS, once per workgroup (its four waves walk the same rows): the kernel's ONLY
   // workgroup barrier; the steps then issue nothing but fragment loads and stores
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
   double *__restrict__ C = Cbase + blk_pos[blk];
   const double *__restrict__ F = Ft + off;
   const double *__restrict__ ph = phi + (int64_t)blk * K;
-  double (*S)[TCW_SLD] = Sall[w];
+  double (*S)[SLD] = Sall[w];
   // k rows of this lane: 4 ks + lq.  EVERY k is clamped to K - 1 BEFORE it forms an address (finite data meets b = 0; K <= 4 NKS, and a
   // small K may leave whole k-steps past it).  A k-step that lies wholly inside K takes a wave-uniform base (SGPRs) + the lane's 32-bit
   // element offset lq ldf + x (the host checks 64 ldf < 2^29): no 64-bit per-lane pointers in registers, one offset per step for all k-steps.
@@ -346,45 +358,49 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
     return base[o + x];
   };
   // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, c0 + 16 jt + li]; k >= K enters as zero
-  double b[4][NKS];
+  double b[NT][NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const double p = (4 * ks + lq < K) ? ph[min(4 * ks + lq, K - 1)] : 0.0;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) b[jt][ks] = p * f_at(ks, (uint32_t)min(c0 + 16 * jt + li, N - 1));
+    for (int jt = 0; jt < NT; ++jt) b[jt][ks] = p * f_at(ks, (uint32_t)min(c0 + 16 * jt + li, N - 1));
   }
-  // store side: lane -> row (l >> 5) + 2 i of a step, columns c0 + 2 (l & 31), + 1
-  const int scol = c0 + 2 * (l & 31);
-  double ecA = -1.0, ecB = -1.0;  // epochs travel through the staging rows as doubles (int32 -> double is exact)
+  // store side: lane -> row l / LPR + RPI i of a step, columns c0 + 2 (l % LPR), + 1
+  const int scol = c0 + 2 * (l % LPR), srow = l / LPR;
+  double ecA = -1.0, ecB = -1.0;  // epochs travel as doubles (int32 -> double is exact)
   if (EP) {
     ecA = scol < N ? (double)epoch_of[off + scol] : -1.0;
     ecB = scol + 1 < N ? (double)epoch_of[off + scol + 1] : -1.0;
   }
   typedef double f64x2 __attribute__((ext_vector_type(2)));
-  double a[NKS];
   const int rfirst = max(rbeg, c0);  // rows above the wave's own columns are not in the lower triangle (both multiples of 16)
   if (rfirst >= rend) return;
+  double a0[NKS], a1[NKS];  // (a1 unused - and optimised away - when DIST == 1)
   {
-    const uint32_t x = (uint32_t)min(rfirst + li, N - 1);
+    const uint32_t x = (uint32_t)min(rfirst + li, N - 1), x1 = (uint32_t)min(rfirst + 16 + li, N - 1);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) a[ks] = f_at(ks, x);
+    for (int ks = 0; ks < NKS; ++ks) a0[ks] = f_at(ks, x);
+    if (DIST == 2) {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) a1[ks] = f_at(ks, x1);
+    }
   }
-  auto step = [&](const int r0) {  // 16 rows x 64 columns; r0 wave-uniform
-    const bool diag_step = r0 < c0 + TCW_COLS;
-    const uint32_t xn = (uint32_t)min(r0 + 16 + li, N - 1);  // the next step's rows (past the segment: clamped, unused)
-    pta_f64x4 acc[4];
+  auto step = [&](const int r0, double (&a)[NKS]) {  // 16 rows x COLS columns; r0 wave-uniform; `a` = the register set holding this step's fragments
+    const bool diag_step = r0 < c0 + COLS;
+    const uint32_t xn = (uint32_t)min(r0 + 16 * DIST + li, N - 1);  // the rows this set serves next (past the segment: clamped, unused)
+    pta_f64x4 acc[NT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) acc[jt] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int jt = 0; jt < NT; ++jt) acc[jt] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
-      a[ks] = f_at(ks, xn);               // the next step's fragment into the register just consumed
-      __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the fifteen loads behind the twelfth group of products)
+      for (int jt = 0; jt < NT; ++jt) acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
+      a[ks] = f_at(ks, xn);               // the fragment of the step DIST ahead into the register just consumed
+      __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the loads behind the twelfth group of products)
     }
-    // 16 x 64 result -> the wave's staging rows (acc[jt][reg] = element (lq + 4 reg, 16 jt + li))
+    // 16 x COLS result -> the wave's staging rows (acc[jt][reg] = element (lq + 4 reg, 16 jt + li))
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) S[lq + 4 * reg][16 * jt + li] = acc[jt][reg];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -392,9 +408,9 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!diag_step && r0 + 16 <= N) {  // wave-uniform: strictly below the diagonal block, all 16 rows exist - nothing is predicated
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rl = (l >> 5) + 2 * i, row = r0 + rl;
-        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l & 31)]);
+      for (int i = 0; i < 16 / RPI; ++i) {
+        const int rl = srow + RPI * i, row = r0 + rl;
+        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l % LPR)]);
         if (EP) {
           const double e2 = Rinfo[row - rbeg][0], er = Repoch[row - rbeg];  // broadcast reads
           v.x = er == ecA ? v.x + e2 : v.x;
@@ -404,9 +420,9 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rl = (l >> 5) + 2 * i, row = r0 + rl;
-        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l & 31)]);
+      for (int i = 0; i < 16 / RPI; ++i) {
+        const int rl = srow + RPI * i, row = r0 + rl;
+        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l % LPR)]);
         const f64x2 rt = *reinterpret_cast<const f64x2 *>(&Rinfo[min(row, rend - 1) - rbeg][0]);  // (ecorr2[row], sigma2[row])
         const double er = Repoch[min(row, rend - 1) - rbeg];
         if (er == ecA && scol <= row) v.x = v.x + rt.x;
@@ -425,21 +441,39 @@ __global__ __launch_bounds__(256, 2) void k_td_cov_walk(const double *__restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();  // the next step's staging writes stay behind these reads
   };
-  // first step peeled: inside the loop the wait in front of a group of products then counts the previous step's stores and the
-  // fragment loads behind it as YOUNGER operations (vmcnt(25)); merged with the kernel's prologue it would insist on vmcnt(14) and make
-  // every step wait for its predecessor's stores
-  step(rfirst);
-  for (int r0 = rfirst + 16; r0 < rend; r0 += 16) step(r0);
+  // first step(s) peeled: inside the loop the wait in front of a group of products then counts the fragment loads behind the one it
+  // needs as YOUNGER operations; merged with the kernel's prologue it would be stricter
+  step(rfirst, a0);
+  if constexpr (DIST == 2) {
+    // steps ALWAYS in pairs (one per register set), no conditional step: every wait inside the loop then sees the same 29 younger loads.
+    // rfirst and a full segment's end are multiples of 32, so only a pulsar's LAST segment can end on an odd step - its extra step lies
+    // wholly at rows >= N: operands clamped, every store predicated off
+    step(rfirst + 16, a1);
+    for (int r0 = rfirst + 32; r0 < rend; r0 += 32) {
+      step(r0, a0);
+      step(r0 + 16, a1);
+    }
+  } else {
+    for (int r0 = rfirst + 16; r0 < rend; r0 += 16) step(r0, a0);
+  }
 }
 
+// variant of the column-walking kernel: 1 = 64 columns per wave, two workgroups per CU, fragments one step ahead; 2 = 128 columns per
+// wave, one workgroup per CU, two steps ahead (K <= 60 only: at 16 k-steps its 512 registers spill - such a K takes variant 1; the
+// 64-column form with two register sets does not fit 256 registers either: 35 spilled, not built).  0 = the default (PTA_TCW_DEFAULT).
+#define PTA_TCW_DEFAULT 1
+static inline int pta_tcw_variant(int v, int K) { return ((v == 0 ? PTA_TCW_DEFAULT : v) == 2 && K <= 60) ? 2 : 1; }
+static inline int pta_tcw_wgcols(int v, int K) { return pta_tcw_variant(v, K) == 2 ? 512 : 256; }
+
 // number of work items of the column-walking kernel per block and in all: item0[b] = first item of block b, item0[n_blocks] = total
-extern "C" int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int32_t *item0_host) {
-  if (!blk_n_host || !item0_host || n_blocks <= 0) return -1;
+extern "C" int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host) {
+  if (!blk_n_host || !item0_host || n_blocks <= 0 || variant < 0 || variant > 2) return -1;
+  const int wgc = pta_tcw_wgcols(variant, K);
   int64_t tot = 0;
   for (int b = 0; b < n_blocks; ++b) {
     item0_host[b] = (int32_t)tot;
     const int n = blk_n_host[b];
-    for (int cb = 0; 256 * cb < n; ++cb) tot += (n - 256 * cb + TCW_SEG - 1) / TCW_SEG;
+    for (int cb = 0; wgc * cb < n; ++cb) tot += (n - wgc * cb + TCW_SEG - 1) / TCW_SEG;
     if (tot >= (1LL << 31)) return -1;
   }
   item0_host[n_blocks] = (int32_t)tot;
@@ -451,22 +485,31 @@ static int pta_td_cov_walk_nks(int K) { return K <= 0 || K > 64 ? 0 : (K > 56 &&
 extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                                         const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                                         const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
-                                        const int32_t *item0, int64_t n_items, void *stream) {
+                                        const int32_t *item0, int64_t n_items, int variant, void *stream) {
   PTA_REQUIRE(Ft && phi && sigma2 && Cbase && blk_pos && blk_ld && blk_n && blk_off && item0, PTA_E_ARG, "pta_td_cov_assemble_walk: NULL argument");
   PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble_walk: ecorr2 missing");
   PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && n_items > 0 && n_items < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_walk: n_blocks=%d n_items=%lld",
               n_blocks, (long long)n_items);
   PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_walk: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
+  PTA_REQUIRE(variant >= 0 && variant <= 2, PTA_E_ARG, "pta_td_cov_assemble_walk: variant=%d (0 .. 2)", variant);
   const int nks = pta_td_cov_walk_nks(K);
   PTA_REQUIRE(nks > 0, PTA_E_ARG, "pta_td_cov_assemble_walk: needs 1 <= K <= 64 (K=%d): use pta_td_cov_assemble_all", K);
   PTA_REQUIRE(ldf > 0 && 64 * ldf < (1LL << 29), PTA_E_ARG, "pta_td_cov_assemble_walk: ldf=%lld too large for 32-bit operand offsets", (long long)ldf);
-#define PTA_TCW_LAUNCH(NKSV)                                                                                                                \
-  if (epoch_of)                                                                                                                             \
-    hipLaunchKernelGGL((k_td_cov_walk<NKSV, true>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,     \
-                       epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks);                                         \
-  else                                                                                                                                      \
-    hipLaunchKernelGGL((k_td_cov_walk<NKSV, false>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2,    \
-                       epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks)
+  const int v = pta_tcw_variant(variant, K);
+#define PTA_TCW_LAUNCH2(NKSV, EPV, NTV, DISTV)                                                                                              \
+  hipLaunchKernelGGL((k_td_cov_walk<NKSV, EPV, NTV, DISTV>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, \
+                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks)
+#define PTA_TCW_LAUNCH1(NKSV, EPV)                        \
+  if (v == 2 && NKSV <= 15)                               \
+    PTA_TCW_LAUNCH2((NKSV <= 15 ? NKSV : 15), EPV, 8, 2); \
+  else                                                    \
+    PTA_TCW_LAUNCH2(NKSV, EPV, 4, 1)
+#define PTA_TCW_LAUNCH(NKSV)      \
+  if (epoch_of) {                 \
+    PTA_TCW_LAUNCH1(NKSV, true);  \
+  } else {                        \
+    PTA_TCW_LAUNCH1(NKSV, false); \
+  }
   switch (nks) {
     case 4: PTA_TCW_LAUNCH(4); break;
     case 8: PTA_TCW_LAUNCH(8); break;
@@ -475,6 +518,8 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
     default: PTA_TCW_LAUNCH(16); break;
   }
 #undef PTA_TCW_LAUNCH
+#undef PTA_TCW_LAUNCH1
+#undef PTA_TCW_LAUNCH2
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }
@@ -627,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
     zrow = pl.z + (int64_t)min(m_a, M - 1) * pl.ld_z + pl.blk_zoff[blk];
     zfetch(0);
   }
+  const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 256)
   auto slab = [&](int s, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int cur = s & 1, k0 = s * TDS_K;
@@ -645,6 +691,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
       pta_normal_pair(seed, real_a, strm_a, p0 + 1u, z[2], z[3], fast);
     }
     const int kq = k0 + 4 * q;  // this lane's first k of the slab
+    const int dlive = MASK ? __builtin_amdgcn_readfirstlane(min(max(s - sdiag, 0), TDS_NT - 1)) : 0;  // first column tile with an element on or below the diagonal
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       pta_f64x2 b[TDS_NT];
@@ -658,11 +705,37 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
           b[j].y = (kq + 2 * half + 1 <= row) ? b[j].y : 0.0;
         }
       }
-#pragma unroll
-      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[2 * half], b[j].x, acc[j]);
+      // MASK slabs: column tile j (rows n0 + 16 j .. + 15 of the factor) lies wholly ABOVE the diagonal from slab sdiag + j + 1 on - its
+      // products would multiply sixteen zeros.  They are skipped with ONE computed jump per run of products (a fall-through switch over
+      // the first live tile d = s - sdiag; MFMAs ignore EXEC, so a real branch it must be): the diagonal slabs are 16 of a strip's ~164
+      // and nearly half of their tile products were of this kind.
+#define PTA_TD_RUN(ZV, BF)                                                                          \
+      if (MASK) {                                                                                   \
+        switch (dlive) {                                                                            \
+          case 0: acc[0] = pta_mfma_f64(ZV, b[0].BF, acc[0]); [[fallthrough]];                      \
+          case 1: acc[1] = pta_mfma_f64(ZV, b[1].BF, acc[1]); [[fallthrough]];                      \
+          case 2: acc[2] = pta_mfma_f64(ZV, b[2].BF, acc[2]); [[fallthrough]];                      \
+          case 3: acc[3] = pta_mfma_f64(ZV, b[3].BF, acc[3]); [[fallthrough]];                      \
+          case 4: acc[4] = pta_mfma_f64(ZV, b[4].BF, acc[4]); [[fallthrough]];                      \
+          case 5: acc[5] = pta_mfma_f64(ZV, b[5].BF, acc[5]); [[fallthrough]];                      \
+          case 6: acc[6] = pta_mfma_f64(ZV, b[6].BF, acc[6]); [[fallthrough]];                      \
+          case 7: acc[7] = pta_mfma_f64(ZV, b[7].BF, acc[7]); [[fallthrough]];                      \
+          case 8: acc[8] = pta_mfma_f64(ZV, b[8].BF, acc[8]); [[fallthrough]];                      \
+          case 9: acc[9] = pta_mfma_f64(ZV, b[9].BF, acc[9]); [[fallthrough]];                      \
+          case 10: acc[10] = pta_mfma_f64(ZV, b[10].BF, acc[10]); [[fallthrough]];                  \
+          case 11: acc[11] = pta_mfma_f64(ZV, b[11].BF, acc[11]); [[fallthrough]];                  \
+          case 12: acc[12] = pta_mfma_f64(ZV, b[12].BF, acc[12]); [[fallthrough]];                  \
+          case 13: acc[13] = pta_mfma_f64(ZV, b[13].BF, acc[13]); [[fallthrough]];                  \
+          case 14: acc[14] = pta_mfma_f64(ZV, b[14].BF, acc[14]); [[fallthrough]];                  \
+          default: acc[15] = pta_mfma_f64(ZV, b[15].BF, acc[15]);                                   \
+        }                                                                                           \
+      } else {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(ZV, b[j].BF, acc[j]); \
+      }
+      PTA_TD_RUN(z[2 * half], x)
       if (half == 0 && s + 1 < nslab) stage(k0 + TDS_K, cur ^ 1);  // behind the first 16 MFMAs; its buffer was last read before the previous barrier
-#pragma unroll
-      for (int j = 0; j < TDS_NT; ++j) acc[j] = pta_mfma_f64(z[2 * half + 1], b[j].y, acc[j]);
+      PTA_TD_RUN(z[2 * half + 1], y)
+#undef PTA_TD_RUN
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the closing barrier (and its vmcnt(0)) behind the MFMAs
     __syncthreads();
@@ -670,7 +743,6 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   stage(0, 0);
   if (!ZMEM) pta_rng_stage_tables();  // Box-Muller tables -> LDS (pta_rng.h)
   __syncthreads();
-  const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 256)
   int s = 0;
   for (; s < min(sdiag, nslab); ++s) slab(s, std::false_type{});
   for (; s < nslab; ++s) slab(s, std::true_type{});

@@ -112,17 +112,18 @@ class TimeDomainMixin:
         if kernel == "walk":
             if not walk_ok:
                 raise ValueError(f"td_cov_kernel='walk' needs 1 <= K <= 64 red-noise columns and 64 n_toa < 2^29 (K={K}, n_toa={N})")
+            variant = int(getattr(self, "td_cov_walk_variant", 0))     # pta_td_cov_assemble_walk: 0 = default, 1 / 2 = its two forms
             items = getattr(self, "_td_walk_items", None)
-            if items is None or items[0] != tuple(counts):
+            if items is None or items[0] != (tuple(counts), K, variant):
                 h_n = np.ascontiguousarray(counts, dtype=np.int32)
                 item0 = np.zeros(P + 1, dtype=np.int32)
-                total = int(_lib.lib.pta_td_cov_walk_items(dv.hptr(h_n), P, dv.hptr(item0)))
+                total = int(_lib.lib.pta_td_cov_walk_items(dv.hptr(h_n), P, K, variant, dv.hptr(item0)))
                 if total <= 0:
                     raise _lib.PtaError("pta_td_cov_walk_items failed")
-                items = self._td_walk_items = (tuple(counts), dv.i32(item0), total)
+                items = self._td_walk_items = ((tuple(counts), K, variant), dv.i32(item0), total)
             _lib.call("pta_td_cov_assemble_walk", dv.ptr(self.d_Ft), N, K, dv.ptr(phi), dv.ptr(self._td_sigma2),
                       dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
-                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, dv.ptr(items[1]), items[2], s)
+                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, dv.ptr(items[1]), items[2], variant, s)
         elif kernel == "tile":
             _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
                       dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,

@@ -15,9 +15,11 @@ eng, psrs, noise = bench.build_engine(68, 5000, seed=20260921)
 eng.prepare_td()
 counts = [int(c) for c in eng.counts]
 cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
-for kname in ("walk", "tile"):
-    eng.td_assemble(kernel=kname)
-    t = min(bench._wall(lambda: eng.td_assemble(kernel=kname)) for _ in range(5))
+KERNELS = (("walk64", "walk", 1), ("walk128", "walk", 2), ("tile", "tile", 0))
+for kname, kern, var in KERNELS:
+    eng.td_cov_walk_variant = var
+    eng.td_assemble(kernel=kern)
+    t = min(bench._wall(lambda: eng.td_assemble(kernel=kern)) for _ in range(5))
     res[f"uniform_68x5000_{kname}"] = {"ms": t * 1e3, "TBps_algorithmic": cov_bytes / t / 1e12}
 if "--ragged" in sys.argv:
     eng.d_Ltd = None
@@ -29,8 +31,9 @@ if "--ragged" in sys.argv:
     eng.prepare()
     eng.prepare_td()
     cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
-    for kname in ("walk", "tile"):
-        eng.td_assemble(kernel=kname)
-        t = min(bench._wall(lambda: eng.td_assemble(kernel=kname)) for _ in range(3))
+    for kname, kern, var in KERNELS:
+        eng.td_cov_walk_variant = var
+        eng.td_assemble(kernel=kern)
+        t = min(bench._wall(lambda: eng.td_assemble(kernel=kern)) for _ in range(3))
         res[f"ragged_ng15like_{kname}"] = {"ms": t * 1e3, "TBps_algorithmic": cov_bytes / t / 1e12}
 print(json.dumps(res))
