@@ -276,7 +276,7 @@ def td_mode_numbers(eng, R):
     # the assembly alone, both kernels, against the ALGORITHMIC bytes (8 per element of the lower triangles, diagonal included)
     cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
     res["cov_assemble_kernel"] = getattr(eng, "td_cov_kernel_used", None)       # what prepare_td() took
-    for kname, kern_, var in (("walk1", "walk", 1), ("walk2", "walk", 2), ("tile", "tile", 0)):
+    for kname, kern_, var in (("walk", "walk", 0), ("tile", "tile", 0)):
         try:
             eng.td_cov_walk_variant = var
             eng.td_assemble(kernel=kern_)
@@ -669,8 +669,7 @@ def compact_line(full):
     flat["td_cov_ms"] = r(td.get("cov_assemble_ms"))
     flat["td_cov_TBps"] = r((td.get("cov_assemble_GBps_lower_triangle") or 0) / 1e3) if td.get("cov_assemble_GBps_lower_triangle") else None
     flat["td_cov_frac_hbm"] = r((td.get("cov_assemble_GBps_lower_triangle") or 0) / HBM_PEAK_GBS) if td.get("cov_assemble_GBps_lower_triangle") else None
-    flat["td_cov_walk64_ms"] = r(td.get("cov_assemble_walk1_ms"))
-    flat["td_cov_walk128_ms"] = r(td.get("cov_assemble_walk2_ms"))
+    flat["td_cov_walk_ms"] = r(td.get("cov_assemble_walk_ms"))
     flat["td_cov_tile_ms"] = r(td.get("cov_assemble_tile_ms"))
     flat["td_potrf_ms"] = r(td.get("potrf_ms"))
     flat["td_potrf_TFLOPs"] = r(td.get("potrf_TFLOPs"), 2)

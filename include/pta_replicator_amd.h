@@ -402,8 +402,8 @@ int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *
  * empty workgroups.  pta_td_cov_walk_items writes item0[b] = first item of block b (b <= n_blocks: item0[n_blocks] = the total,
  * also returned; -1 on a bad argument) from the HOST copy of the orders; the caller keeps a device copy of item0 for the launch.
  * Every k index is clamped to K - 1 before it forms an address: nothing behind the [K, ldf] design matrix is ever read.
- * variant (the SAME K and variant for both calls): 0 = default; 1 = 64 columns per wave, two workgroups per CU, fragments requested one
- * step ahead; 2 = 128 columns per wave, one workgroup per CU, two steps ahead (K <= 60; work items cover 512 columns).            */
+ * variant (the SAME K and variant for both calls): 0 = default, 1 = 64 columns per wave (the only form built; the argument is reserved
+ * for further work-item geometries).                                                                                              */
 int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host);
 int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                              const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,

@@ -12,7 +12,8 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint3
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpta_replicator_amd.so")
+# PTA_REPLICATOR_AMD_LIB: an explicitly named build of the SAME library (probe builds with diagnostic defines: scripts/probe_src/) - never a fallback
+LIB_PATH = os.environ.get("PTA_REPLICATOR_AMD_LIB") or os.path.join(_HERE, "libpta_replicator_amd.so")
 
 
 class PtaError(RuntimeError):

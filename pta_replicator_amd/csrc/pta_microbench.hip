@@ -19,6 +19,30 @@ __global__ __launch_bounds__(256) void k_mb_mfma(double *out, int iters) {
   if (s == 123.456) out[0] = s;
 }
 
+// how many INDEPENDENT accumulators does a wave need to keep the fp64 matrix pipe busy?  NACC accumulators, each product with its own
+// B operand and a shared A operand (the pattern of a wave that walks rows against resident columns), back to back (kind 8; option = NACC,
+// bytes = workgroups per CU = waves per SIMD)
+template <int NACC>
+__global__ __launch_bounds__(256, 2) void k_mb_mfma_nacc(double *out, int iters) {
+  pta_f64x4 acc[NACC];
+  double b[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    acc[i] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
+    b[i] = 1.0 - (threadIdx.x + 32 * i) * 1e-9;
+  }
+  double a = 1.0 + threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = pta_mfma_f64(a, b[i], acc[i]);
+    a = a + 1e-12;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 123.456) out[0] = s;
+}
+
 // the register-tile pattern of the GEMM kernels: 4 A fragments x 4 B fragments -> 16 accumulators, acc[i][j] += a[i] b[j]
 // (16 independent MFMAs between two uses of an accumulator, operands change from one instruction to the next)
 __global__ __launch_bounds__(256, 2) void k_mb_mfma_tile(double *out, int iters) {
@@ -106,6 +130,30 @@ __global__ void k_mb_write(double2 *out, int64_t n2) {
   for (; i < n2; i += stride) out[i] = v;
 }
 
+// the STORE PATTERN of the walking assembly kernel without its arithmetic (kind 7): a wave owns a strip of `strip2` double2 columns (16 bytes
+// each: 32 -> 512-byte row segments) of a [rows, ld2]-double2 matrix and walks down `seg_rows` rows, every store instruction writing
+// 64 / strip2 whole row segments; the four waves of a workgroup own four neighbouring strips of the same rows.  What HBM takes when 2048
+// waves write row segments 40 KB apart - the ceiling k_td_cov_walk's stores can reach, as opposed to the contiguous stream of k_mb_write.
+__global__ __launch_bounds__(256) void k_mb_write_strips(double2 *__restrict__ out, int64_t ld2, int rows, int strip2, int nstrips, int seg_rows, int64_t blk2, int64_t nblk) {
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + w;
+  const int strip = (int)(gw % nstrips);
+  const int nseg = (rows + seg_rows - 1) / seg_rows;
+  const int seg = (int)((gw / nstrips) % nseg);
+  const int64_t b = gw / ((int64_t)nstrips * nseg);
+  if (b >= nblk) return;
+  double2 *__restrict__ M = out + b * blk2;
+  const double2 v = make_double2(1.0 + l, 2.0);
+  const int r0 = seg * seg_rows, r1 = min(rows, r0 + seg_rows);
+  if (strip2 <= 64) {
+    const int rpi = 64 / strip2, lr = l / strip2, lc = l % strip2;
+    for (int r = r0 + lr; r < r1; r += rpi) M[(int64_t)r * ld2 + (int64_t)strip * strip2 + lc] = v;
+  } else {
+    for (int r = r0; r < r1; ++r)
+      for (int c = l; c < strip2; c += 64) M[(int64_t)r * ld2 + (int64_t)strip * strip2 + c] = v;
+  }
+}
+
 __global__ void k_mb_copy(const double2 *__restrict__ in, double2 *__restrict__ out, int64_t n2) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -142,18 +190,25 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
   PTA_HIP(hipGetDeviceProperties(&prop, dev));
   const int cus = prop.multiProcessorCount;
   // kinds 0/1/4: `bytes` in 1..32 selects the number of 256-thread blocks per CU (= waves per SIMD); default 8
-  const int bpc = ((kind == 0 || kind == 1 || kind == 4 || kind == 5 || kind == 6) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
+  const int bpc = ((kind == 0 || kind == 1 || kind == 4 || kind == 5 || kind == 6 || kind == 8) && bytes >= 1 && bytes <= 32) ? (int)bytes : 8;
+  // kind 7: `option` = bytes per row segment (256 .. 8192), `bytes` = total bytes written per launch (blocks of 5000 x 5008 doubles)
+  const int s7_rows = 5000, s7_ld2 = 5008 / 2;
+  const int s7_seg = option & 0xFFFF, s7_lds = (option >> 16) * 1024;  // option = bytes per row segment | (KB of dynamic LDS per workgroup << 16): 70 KB -> two workgroups per CU, as k_td_cov_walk
+  const int s7_strip2 = kind == 7 ? (s7_seg >= 16 ? s7_seg / 16 : 32) : 32;
+  const int s7_nstrips = s7_ld2 / s7_strip2;
+  const int64_t s7_blk2 = (int64_t)s7_rows * s7_ld2;
+  const int64_t s7_nblk = kind == 7 ? (bytes / (s7_blk2 * 16) > 0 ? bytes / (s7_blk2 * 16) : 1) : 0;
   hipEvent_t e0, e1;
   PTA_HIP(hipEventCreate(&e0));
   PTA_HIP(hipEventCreate(&e1));
   double *buf = nullptr, *buf2 = nullptr;
-  int64_t nbytes = (kind == 2 || kind == 3) ? bytes : 4096;
+  int64_t nbytes = (kind == 2 || kind == 3) ? bytes : (kind == 7 ? s7_nblk * s7_blk2 * 16 : 4096);
   PTA_REQUIRE(nbytes >= 4096, PTA_E_ARG, "pta_microbench: bytes too small");
   PTA_HIP(hipMalloc(&buf, nbytes));
   if (kind == 3) PTA_HIP(hipMalloc(&buf2, nbytes));
   float ms = 0.f;
   double work = 0.0;
-  const int reps = (kind == 2 || kind == 3) ? iters : 3;
+  const int reps = (kind == 2 || kind == 3 || kind == 7) ? iters : 3;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0 = warm-up
     PTA_HIP(hipEventRecord(e0, 0));
     for (int rep = 0; rep < reps; ++rep) {
@@ -182,6 +237,25 @@ extern "C" int pta_microbench(int kind, int64_t bytes, int iters, int option, do
           hipLaunchKernelGGL(k_mb_copy, dim3(cus * 8), dim3(256), 0, 0, (const double2 *)buf2, (double2 *)buf, nbytes / 16);
           work = 2.0 * (double)nbytes * reps;
           break;
+        case 7: {
+          const int nseg = (s7_rows + 511) / 512;
+          const int64_t waves = s7_nblk * nseg * s7_nstrips;
+          hipLaunchKernelGGL(k_mb_write_strips, dim3((unsigned)((waves + 3) / 4)), dim3(256), s7_lds, 0, (double2 *)buf, (int64_t)s7_ld2, s7_rows, s7_strip2,
+                             s7_nstrips, 512, s7_blk2, s7_nblk);
+          work = (double)s7_nblk * s7_rows * s7_nstrips * s7_strip2 * 16.0 * reps;
+          break;
+        }
+        case 8: {
+          const int na = option;
+          if (na == 1) hipLaunchKernelGGL(k_mb_mfma_nacc<1>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          else if (na == 2) hipLaunchKernelGGL(k_mb_mfma_nacc<2>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          else if (na == 4) hipLaunchKernelGGL(k_mb_mfma_nacc<4>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          else if (na == 8) hipLaunchKernelGGL(k_mb_mfma_nacc<8>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          else if (na == 12) hipLaunchKernelGGL(k_mb_mfma_nacc<12>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          else hipLaunchKernelGGL(k_mb_mfma_nacc<16>, dim3(cus * bpc), dim3(256), 0, 0, buf, iters);
+          work = (double)cus * bpc * 4 * iters * (double)(na == 1 || na == 2 || na == 4 || na == 8 || na == 12 ? na : 16) * 2048.0 * reps;
+          break;
+        }
         case 4:
           hipLaunchKernelGGL(k_mb_rng, dim3(cus * bpc), dim3(256), 0, 0, buf, iters, option);
           work = (double)cus * bpc * 256 * iters * 2.0 * reps;  // normals

@@ -271,10 +271,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // segment of TCW_SEG rows: its B operand - phi_k F[k, col], 4 column tiles x NKS k-steps - is loaded ONCE into registers (120 VGPRs at
 // K = 60) and stays there while the wave walks down the rows 16 at a time.  Per step: the A fragments of the NEXT step are requested
 // straight from the K-major design matrix (a lane's value F[4 ks + (l >> 4), row0 + (l & 15)]: four 128-byte row pieces per load, L1 /
-// L2 hits - a pulsar's F is 2.4 MB), 4 x NKS MFMAs, then the 16 x 64 result is turned through a WAVE-PRIVATE piece of LDS (no workgroup
-// barrier anywhere in the kernel: a wave's LDS operations execute in order) so that every store instruction writes two whole 512-byte
-// row segments, with the white / ECORR terms added on the way out.  Stores of step s drain under the products of steps s + 1, s + 2:
-// nothing waits for them until the wave retires, 32 steps later.
+// L2 hits - a pulsar's F is 2.4 MB), 4 x NKS MFMAs, then the white / ECORR terms are added in the accumulators' own layout and the 16 x 64
+// result goes straight to memory: the column tiles are interleaved in pairs (see the B operand), so a lane owns two NEIGHBOURING columns
+// and a store instruction writes four rows x 256 bytes of whole cache lines.  No LDS staging, no barrier inside the walk; the stores of
+// step s drain under the products of the following steps.
 //
 // Round 4's first column-walking kernel (32 columns per wave, 128-byte store pieces; commit ee73ef5, withdrawn in 18da960) "produced NaN
 // until a device-wide synchronisation" in one test sequence.  Cause (round 5; scripts/gpu_r5_nan_repro.py reproduces it on demand): for
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // allocation history - a synchronisation with its frees included - moved finite bytes there and the symptom vanished.  No ordering
 // hazard was involved.  Here every k index is clamped to K - 1 (finite data) before it forms an address, and the tests run the kernel
 // on an Ft that is a view into a NaN-filled slab.
-#define TCW_SEG 512
+#define TCW_SEG_MAX 1024   // rows per work item: 512 or 1024 (host: pta_tcw_seg)
 // NT = 16-column tiles a wave owns (4: 64 columns, two workgroups per CU, 226-240 VGPRs; 8: 128 columns, ONE workgroup per CU with the
 // whole 512-entry register file per wave - 1 KB row segments per store, half the fragment traffic per byte written).  DIST = how many
 // steps ahead the A fragments are requested (a ring of DIST register sets, each set reloading itself for the step DIST ahead as its
@@ -294,21 +294,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // loads are still in flight (an L2 hit takes ~9 groups of products), which leaves room for ~5 outstanding 1 KB stores per wave - 10 MB
 // over the chip, Little's law for ~3 TB/s at the ~3 us a store takes to be acknowledged under load: the 2.96 TB/s measured.  DIST = 2
 // triples the allowance.
-template <int NKS, bool EP, int NT, int DIST>
+// DIAG (probe builds only, -DPTA_TCW_DIAG; results are WRONG by construction): 1 = no global stores, 2 = no fragment loads inside the
+// steps, 3 = no products - which of the three streams bounds the kernel (scripts/gpu_r5_tcw_diag.py)
+template <int NKS, bool EP, int NT, int DIST, int DIAG = 0>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
                                                         const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
                                                         const double *__restrict__ ecorr2, double *__restrict__ Cbase,
                                                         const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
                                                         const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off,
-                                                        const int32_t *__restrict__ item0, int n_blocks) {
+                                                        const int32_t *__restrict__ item0, int n_blocks, int seg_rows) {
   constexpr int COLS = 16 * NT;        // columns per wave
   constexpr int WGC = 4 * COLS;        // columns per workgroup
-  constexpr int SLD = COLS + 16;       // staging pitch (doubles) == 16 (mod 32): the two quarter-waves of a ds_write_b64 hit disjoint bank halves
-  constexpr int LPR = COLS / 2;        // lanes per stored row (two columns each)
-  constexpr int RPI = 64 / LPR;        // rows per store instruction
-  __shared__ double __attribute__((aligned(16))) Sall[4][16][SLD];
-  __shared__ double __attribute__((aligned(16))) Rinfo[TCW_SEG][2];  // (ecorr2, sigma2) of the segment's rows
-  __shared__ double Repoch[TCW_SEG];                                 // their epochs (int32 -> double is exact)
+  static_assert(NT % 2 == 0, "column tiles come in pairs (a lane's two neighbouring columns)");
+  __shared__ double __attribute__((aligned(16))) Rinfo[TCW_SEG_MAX][2];  // (ecorr2, sigma2) of the segment's rows
+  __shared__ double Repoch[TCW_SEG_MAX];                                 // their epochs (int32 -> double is exact)
   // work item -> (pulsar, WGC-column group, row segment); item0[b] = first item of pulsar b (host: pta_td_cov_walk_items)
   int blk = 0;
   {
@@ -322,20 +321,19 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   const int N = blk_n[blk];
   int item = (int)blockIdx.x - item0[blk], cb = 0;
   for (;; ++cb) {  // workgroup-uniform
-    const int ns = (N - WGC * cb + TCW_SEG - 1) / TCW_SEG;
+    const int ns = (N - WGC * cb + seg_rows - 1) / seg_rows;
     if (item < ns) break;
     item -= ns;
     if (WGC * (cb + 1) >= N) return;  // (cannot happen with a consistent item table)
   }
   const int t = threadIdx.x, l = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = l & 15, lq = l >> 4;
   const int c0 = WGC * cb + COLS * w;  // this wave's columns
-  const int rbeg = WGC * cb + TCW_SEG * item, rend = min(N, rbeg + TCW_SEG);
+  const int rbeg = WGC * cb + seg_rows * item, rend = min(N, rbeg + seg_rows);
   const int64_t off = blk_off[blk];
   // the white / ECORR terms of the segment's rows -> LDS, once per workgroup (its four waves walk the same rows): the kernel's ONLY
   // workgroup barrier; the steps then issue nothing but fragment loads and stores
-#pragma unroll
-  for (int i = 0; i < TCW_SEG / 256; ++i) {
-    const int rr = t + 256 * i, row = min(rbeg + rr, N - 1);
+  for (int rr = t; rr < seg_rows; rr += 256) {
+    const int row = min(rbeg + rr, N - 1);
     Rinfo[rr][0] = EP ? ecorr2[off + row] : 0.0;
     Rinfo[rr][1] = sigma2[off + row];
     Repoch[rr] = EP ? (double)epoch_of[off + row] : -2.0;
@@ -346,7 +344,6 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   double *__restrict__ C = Cbase + blk_pos[blk];
   const double *__restrict__ F = Ft + off;
   const double *__restrict__ ph = phi + (int64_t)blk * K;
-  double (*S)[SLD] = Sall[w];
   // k rows of this lane: 4 ks + lq.  EVERY k is clamped to K - 1 BEFORE it forms an address (finite data meets b = 0; K <= 4 NKS, and a
   // small K may leave whole k-steps past it).  A k-step that lies wholly inside K takes a wave-uniform base (SGPRs) + the lane's 32-bit
   // element offset lq ldf + x (the host checks 64 ldf < 2^29): no 64-bit per-lane pointers in registers, one offset per step for all k-steps.
@@ -357,21 +354,28 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
     const uint32_t o = whole ? lqo : (uint32_t)min(4 * ks + lq, K - 1) * (uint32_t)ldf;
     return base[o + x];
   };
-  // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, c0 + 16 jt + li]; k >= K enters as zero
+  // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, col(jt, li)]; k >= K enters as zero.  The sixteen columns of MFMA
+  // tile jt are NOT sixteen neighbours: col(jt, li) = c0 + 32 (jt >> 1) + 2 li + (jt & 1) - tiles 2 p and 2 p + 1 interleave, so that a lane's
+  // accumulators (row q + 4 reg, its column of tile jt) hold TWO NEIGHBOURING columns per tile pair: the result goes from the accumulators
+  // straight to memory as 16-byte stores, sixteen lanes = one 256-byte piece of a row, four rows per instruction - whole 128-byte lines,
+  // no transposition through LDS (pta_microbench kind 7: HBM takes row pieces of 128 bytes ... 4 KB at the same 5.4-5.6 TB/s).
   double b[NT][NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const double p = (4 * ks + lq < K) ? ph[min(4 * ks + lq, K - 1)] : 0.0;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) b[jt][ks] = p * f_at(ks, (uint32_t)min(c0 + 16 * jt + li, N - 1));
+    for (int jt = 0; jt < NT; ++jt) b[jt][ks] = p * f_at(ks, (uint32_t)min(c0 + 32 * (jt >> 1) + 2 * li + (jt & 1), N - 1));
   }
-  // store side: lane -> row l / LPR + RPI i of a step, columns c0 + 2 (l % LPR), + 1
-  const int scol = c0 + 2 * (l % LPR), srow = l / LPR;
-  double ecA = -1.0, ecB = -1.0;  // epochs travel as doubles (int32 -> double is exact)
-  if (EP) {
-    ecA = scol < N ? (double)epoch_of[off + scol] : -1.0;
-    ecB = scol + 1 < N ? (double)epoch_of[off + scol + 1] : -1.0;
-  }
+  // store side: lane (lq, li) -> rows lq + 4 reg of a step, columns c0 + 32 p + 2 li, + 1 for p < NT / 2
+  const int scol0 = c0 + 2 * li;
+  double ec[NT / 2][2];  // epochs of the lane's columns, as doubles (int32 -> double is exact); -1 past the block
+#pragma unroll
+  for (int pp = 0; pp < NT / 2; ++pp)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = scol0 + 32 * pp + h;
+      ec[pp][h] = (EP && col < N) ? (double)epoch_of[off + col] : -1.0;
+    }
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   const int rfirst = max(rbeg, c0);  // rows above the wave's own columns are not in the lower triangle (both multiples of 16)
   if (rfirst >= rend) return;
@@ -394,52 +398,66 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt) acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
-      a[ks] = f_at(ks, xn);               // the fragment of the step DIST ahead into the register just consumed
+      for (int jt = 0; jt < NT; ++jt) {
+        if (DIAG == 3) acc[jt][ks & 3] = fma(a[ks], b[jt][ks], acc[jt][ks & 3]);
+        else acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
+      }
+      if (DIAG != 2 && DIAG != 5) a[ks] = f_at(ks, xn);  // the fragment of the step DIST ahead into the register just consumed
       __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the loads behind the twelfth group of products)
     }
-    // 16 x COLS result -> the wave's staging rows (acc[jt][reg] = element (lq + 4 reg, 16 jt + li))
+    if (DIAG == 4 || DIAG == 5) {  // no epilogue at all: the products (and, 4, their fragment loads) alone
+      double sacc = 0.0;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) S[lq + 4 * reg][16 * jt + li] = acc[jt][reg];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int jt = 0; jt < NT; ++jt) sacc += acc[jt][0] + acc[jt][1] + acc[jt][2] + acc[jt][3];
+      if (sacc == 1.2345e300) C[0] = sacc;
+      return;
+    }
+    // epilogue: white / ECORR terms added in the accumulators' own layout, then 16-byte stores (see the B operand above)
     if (!diag_step && r0 + 16 <= N) {  // wave-uniform: strictly below the diagonal block, all 16 rows exist - nothing is predicated
 #pragma unroll
-      for (int i = 0; i < 16 / RPI; ++i) {
-        const int rl = srow + RPI * i, row = r0 + rl;
-        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l % LPR)]);
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + lq + 4 * reg;
+        double e2 = 0.0, er = -2.0;
         if (EP) {
-          const double e2 = Rinfo[row - rbeg][0], er = Repoch[row - rbeg];  // broadcast reads
-          v.x = er == ecA ? v.x + e2 : v.x;
-          v.y = er == ecB ? v.y + e2 : v.y;
+          e2 = Rinfo[row - rbeg][0];   // (four distinct rows per wave: broadcast reads)
+          er = Repoch[row - rbeg];
         }
-        *reinterpret_cast<f64x2 *>(C + (int64_t)row * ldc + scol) = v;
+        double *__restrict__ dst = C + (int64_t)row * ldc + scol0;
+#pragma unroll
+        for (int pp = 0; pp < NT / 2; ++pp) {
+          f64x2 v = {acc[2 * pp][reg], acc[2 * pp + 1][reg]};
+          if (EP) {
+            v.x = er == ec[pp][0] ? v.x + e2 : v.x;
+            v.y = er == ec[pp][1] ? v.y + e2 : v.y;
+          }
+          if (DIAG != 1) *reinterpret_cast<f64x2 *>(dst + 32 * pp) = v;
+          else if (v.x == 1.2345e300) C[0] = v.y;
+        }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16 / RPI; ++i) {
-        const int rl = srow + RPI * i, row = r0 + rl;
-        f64x2 v = *reinterpret_cast<const f64x2 *>(&S[rl][2 * (l % LPR)]);
-        const f64x2 rt = *reinterpret_cast<const f64x2 *>(&Rinfo[min(row, rend - 1) - rbeg][0]);  // (ecorr2[row], sigma2[row])
-        const double er = Repoch[min(row, rend - 1) - rbeg];
-        if (er == ecA && scol <= row) v.x = v.x + rt.x;
-        if (er == ecB && scol + 1 <= row) v.y = v.y + rt.x;
-        if (scol == row) v.x = v.x + rt.y;
-        if (scol + 1 == row) v.y = v.y + rt.y;
-        double *__restrict__ dst = C + (int64_t)row * ldc + scol;
-        if (row < N) {
-          if (scol + 1 <= row)
-            *reinterpret_cast<f64x2 *>(dst) = v;
-          else if (scol == row)
-            dst[0] = v.x;
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = r0 + lq + 4 * reg, rr = min(row, rend - 1) - rbeg;
+        const f64x2 rt = *reinterpret_cast<const f64x2 *>(&Rinfo[rr][0]);  // (ecorr2[row], sigma2[row])
+        const double er = Repoch[rr];
+        double *__restrict__ dst = C + (int64_t)row * ldc + scol0;
+#pragma unroll
+        for (int pp = 0; pp < NT / 2; ++pp) {
+          const int col = scol0 + 32 * pp;
+          f64x2 v = {acc[2 * pp][reg], acc[2 * pp + 1][reg]};
+          if (er == ec[pp][0] && col <= row) v.x = v.x + rt.x;
+          if (er == ec[pp][1] && col + 1 <= row) v.y = v.y + rt.x;
+          if (col == row) v.x = v.x + rt.y;
+          if (col + 1 == row) v.y = v.y + rt.y;
+          if (row < N) {
+            if (col + 1 <= row)
+              *reinterpret_cast<f64x2 *>(dst + 32 * pp) = v;
+            else if (col == row)
+              dst[32 * pp] = v.x;
+          }
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the next step's staging writes stay behind these reads
   };
   // first step(s) peeled: inside the loop the wait in front of a group of products then counts the fragment loads behind the one it
   // needs as YOUNGER operations; merged with the kernel's prologue it would be stricter
@@ -458,22 +476,26 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   }
 }
 
-// variant of the column-walking kernel: 1 = 64 columns per wave, two workgroups per CU, fragments one step ahead; 2 = 128 columns per
-// wave, one workgroup per CU, two steps ahead (K <= 60 only: at 16 k-steps its 512 registers spill - such a K takes variant 1; the
-// 64-column form with two register sets does not fit 256 registers either: 35 spilled, not built).  0 = the default (PTA_TCW_DEFAULT).
-#define PTA_TCW_DEFAULT 1
-static inline int pta_tcw_variant(int v, int K) { return ((v == 0 ? PTA_TCW_DEFAULT : v) == 2 && K <= 60) ? 2 : 1; }
-static inline int pta_tcw_wgcols(int v, int K) { return pta_tcw_variant(v, K) == 2 ? 512 : 256; }
+// variant of the column-walking kernel: 0 / 1 = 64 columns per wave, two workgroups per CU, fragments one step ahead (the only form built).
+// Measured and not kept (profiles/r05_tcw_variants.txt): 128 columns per wave with fragments two steps ahead (NT = 8, DIST = 2: one
+// workgroup per CU, 506 registers, vmcnt(29) waits) - 2.67 against 2.33 ms, a single wave per SIMD exposes every stall; 64 columns with
+// two register sets does not fit 256 registers (35 spilled).
+static inline int pta_tcw_variant(int v, int K) { (void)v; (void)K; return 1; }
+static inline int pta_tcw_wgcols(int v, int K) { (void)v; (void)K; return 256; }
+static inline int pta_tcw_seg(int v) { return v == 2 ? 1024 : 512; }  // rows per work item (A/B: variant 2 = 1024)
 
 // number of work items of the column-walking kernel per block and in all: item0[b] = first item of block b, item0[n_blocks] = total
 extern "C" int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host) {
+#ifdef PTA_TCW_DIAG
+  variant &= 15;
+#endif
   if (!blk_n_host || !item0_host || n_blocks <= 0 || variant < 0 || variant > 2) return -1;
-  const int wgc = pta_tcw_wgcols(variant, K);
+  const int wgc = pta_tcw_wgcols(variant, K), seg = pta_tcw_seg(variant);
   int64_t tot = 0;
   for (int b = 0; b < n_blocks; ++b) {
     item0_host[b] = (int32_t)tot;
     const int n = blk_n_host[b];
-    for (int cb = 0; wgc * cb < n; ++cb) tot += (n - wgc * cb + TCW_SEG - 1) / TCW_SEG;
+    for (int cb = 0; wgc * cb < n; ++cb) tot += (n - wgc * cb + seg - 1) / seg;
     if (tot >= (1LL << 31)) return -1;
   }
   item0_host[n_blocks] = (int32_t)tot;
@@ -491,6 +513,10 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && n_items > 0 && n_items < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_walk: n_blocks=%d n_items=%lld",
               n_blocks, (long long)n_items);
   PTA_REQUIRE(((uintptr_t)Cbase % 16) == 0, PTA_E_ARG, "pta_td_cov_assemble_walk: Cbase must be 16-byte aligned (blk_pos and blk_ld even)");
+#ifdef PTA_TCW_DIAG
+  const int diag = variant >> 4;
+  variant &= 15;
+#endif
   PTA_REQUIRE(variant >= 0 && variant <= 2, PTA_E_ARG, "pta_td_cov_assemble_walk: variant=%d (0 .. 2)", variant);
   const int nks = pta_td_cov_walk_nks(K);
   PTA_REQUIRE(nks > 0, PTA_E_ARG, "pta_td_cov_assemble_walk: needs 1 <= K <= 64 (K=%d): use pta_td_cov_assemble_all", K);
@@ -498,18 +524,23 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   const int v = pta_tcw_variant(variant, K);
 #define PTA_TCW_LAUNCH2(NKSV, EPV, NTV, DISTV)                                                                                              \
   hipLaunchKernelGGL((k_td_cov_walk<NKSV, EPV, NTV, DISTV>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, \
-                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks)
-#define PTA_TCW_LAUNCH1(NKSV, EPV)                        \
-  if (v == 2 && NKSV <= 15)                               \
-    PTA_TCW_LAUNCH2((NKSV <= 15 ? NKSV : 15), EPV, 8, 2); \
-  else                                                    \
-    PTA_TCW_LAUNCH2(NKSV, EPV, 4, 1)
+                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant))
+#define PTA_TCW_LAUNCH1(NKSV, EPV) PTA_TCW_LAUNCH2(NKSV, EPV, 4, 1)
 #define PTA_TCW_LAUNCH(NKSV)      \
   if (epoch_of) {                 \
     PTA_TCW_LAUNCH1(NKSV, true);  \
   } else {                        \
     PTA_TCW_LAUNCH1(NKSV, false); \
   }
+#ifdef PTA_TCW_DIAG
+  if (diag && nks == 15 && epoch_of) {
+#define PTA_TCW_D(NTV, DISTV, DG) hipLaunchKernelGGL((k_td_cov_walk<15, true, NTV, DISTV, DG>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant))
+    { if (diag == 1) PTA_TCW_D(4, 1, 1); else if (diag == 2) PTA_TCW_D(4, 1, 2); else if (diag == 3) PTA_TCW_D(4, 1, 3); else if (diag == 4) PTA_TCW_D(4, 1, 4); else PTA_TCW_D(4, 1, 5); }
+#undef PTA_TCW_D
+    PTA_LAUNCH_CHECK();
+    return PTA_OK;
+  }
+#endif
   switch (nks) {
     case 4: PTA_TCW_LAUNCH(4); break;
     case 8: PTA_TCW_LAUNCH(8); break;

@@ -15,11 +15,11 @@ eng, psrs, noise = bench.build_engine(68, 5000, seed=20260921)
 eng.prepare_td()
 counts = [int(c) for c in eng.counts]
 cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
-KERNELS = (("walk64", "walk", 1), ("walk128", "walk", 2), ("tile", "tile", 0))
+KERNELS = (("walk", "walk", 0), ("walk_seg1024", "walk", 2), ("tile", "tile", 0))
 for kname, kern, var in KERNELS:
     eng.td_cov_walk_variant = var
     eng.td_assemble(kernel=kern)
-    t = min(bench._wall(lambda: eng.td_assemble(kernel=kern)) for _ in range(5))
+    t = min(bench._wall(lambda: eng.td_assemble(kernel=kern)) for _ in range(8))
     res[f"uniform_68x5000_{kname}"] = {"ms": t * 1e3, "TBps_algorithmic": cov_bytes / t / 1e12}
 if "--ragged" in sys.argv:
     eng.d_Ltd = None

@@ -209,10 +209,13 @@ def test_config5_ska_scale_anisotropic():
         make_ideal(psr)
         psrs.append(psr)
     locs = po.psr_locs_equatorial([p.loc for p in psrs])
+    anis.correlated_basis_device(locs[:8], lmax)                       # first launch of the kernel (code object load) outside the timing
     torch.cuda.synchronize(); t0 = time.perf_counter()
     basis = anis.correlated_basis_device(locs, lmax)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    assert dt < 5.0
+    # measured (bench.py orf_numbers, profiles/r05_bench_final.json): pta_orf_basis 0.39 ms + pta_orf_combine 0.005 ms on the device, 65 ms
+    # of host pair-separation loop (the reference's own scalar arithmetic, kept on the host) - 12-15 min in the reference; bound = ~10x
+    assert dt < 0.7, dt
     basis = basis.cpu().numpy()
     assert basis.shape == (25, P, P) and np.all(np.isfinite(basis)) and np.allclose(basis, basis.transpose(0, 2, 1), rtol=0, atol=0)
     for (a, b) in ((0, 0), (3, 77), (150, 199), (42, 43), (9, 120)):
