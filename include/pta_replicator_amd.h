@@ -402,13 +402,14 @@ int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *
  * empty workgroups.  pta_td_cov_walk_items writes item0[b] = first item of block b (b <= n_blocks: item0[n_blocks] = the total,
  * also returned; -1 on a bad argument) from the HOST copy of the orders; the caller keeps a device copy of item0 for the launch.
  * Every k index is clamped to K - 1 before it forms an address: nothing behind the [K, ldf] design matrix is ever read.
- * variant (the SAME K and variant for both calls): 0 = default, 1 = 64 columns per wave (the only form built; the argument is reserved
- * for further work-item geometries).                                                                                              */
+ * epoch_first (optional, device, indexed like epoch_of): the smallest TOA index INSIDE ITS BLOCK that shares the TOA's epoch - lets a step
+ * whose rows have no epoch partner among the wave's columns skip the ECORR arithmetic (every step off the diagonal for time-ordered
+ * TOAs); NULL keeps it everywhere.  variant (the SAME K and variant for both calls): 0 / 1 (reserved for further work-item geometries). */
 int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host);
 int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                              const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                              const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
-                             const int32_t *item0, int64_t n_items, int variant, void *stream);
+                             const int32_t *item0, int64_t n_items, const int32_t *epoch_first, int variant, void *stream);
 
 /* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or

@@ -108,7 +108,7 @@ _SIGNATURES = {
     "pta_td_cov_assemble": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "pta_td_cov_assemble_all": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "pta_td_cov_walk_items": (c_int64, [_P, c_int, c_int, c_int, _P]),
-    "pta_td_cov_assemble_walk": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int64, c_int, _P]),
+    "pta_td_cov_assemble_walk": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int64, _P, c_int, _P]),
     "pta_td_trmm": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, c_int64, c_int, c_int, _P]),
     "pta_td_trmm_rng": (c_int, [POINTER(TdPlan), c_uint64, c_uint64, c_int, _P, c_int64, _P]),
     "pta_tm_project": (c_int, [_P, _P, c_int64, c_int, _P, c_int, _P, c_int64, c_int, _P]),

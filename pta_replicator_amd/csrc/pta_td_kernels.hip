@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // allocation history - a synchronisation with its frees included - moved finite bytes there and the symptom vanished.  No ordering
 // hazard was involved.  Here every k index is clamped to K - 1 (finite data) before it forms an address, and the tests run the kernel
 // on an Ft that is a view into a NaN-filled slab.
-#define TCW_SEG_MAX 1024   // rows per work item: 512 or 1024 (host: pta_tcw_seg)
+#define TCW_SEG_MAX 512    // rows per work item (1024 measured 3 % slower: profiles/r05_tcw_diag.txt)
 // NT = 16-column tiles a wave owns (4: 64 columns, two workgroups per CU, 226-240 VGPRs; 8: 128 columns, ONE workgroup per CU with the
 // whole 512-entry register file per wave - 1 KB row segments per store, half the fragment traffic per byte written).  DIST = how many
 // steps ahead the A fragments are requested (a ring of DIST register sets, each set reloading itself for the step DIST ahead as its
@@ -302,12 +302,13 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
                                                         const double *__restrict__ ecorr2, double *__restrict__ Cbase,
                                                         const int64_t *__restrict__ blk_pos, const int32_t *__restrict__ blk_ld,
                                                         const int32_t *__restrict__ blk_n, const int32_t *__restrict__ blk_off,
-                                                        const int32_t *__restrict__ item0, int n_blocks, int seg_rows) {
+                                                        const int32_t *__restrict__ item0, int n_blocks, int seg_rows, const int32_t *__restrict__ epoch_first) {
   constexpr int COLS = 16 * NT;        // columns per wave
   constexpr int WGC = 4 * COLS;        // columns per workgroup
   static_assert(NT % 2 == 0, "column tiles come in pairs (a lane's two neighbouring columns)");
   __shared__ double __attribute__((aligned(16))) Rinfo[TCW_SEG_MAX][2];  // (ecorr2, sigma2) of the segment's rows
   __shared__ double Repoch[TCW_SEG_MAX];                                 // their epochs (int32 -> double is exact)
+  __shared__ int Rlo16[TCW_SEG_MAX / 16];                                // per 16-row step: the smallest column that shares an epoch with one of its rows
   // work item -> (pulsar, WGC-column group, row segment); item0[b] = first item of pulsar b (host: pta_td_cov_walk_items)
   int blk = 0;
   {
@@ -337,6 +338,21 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
     Rinfo[rr][0] = EP ? ecorr2[off + row] : 0.0;
     Rinfo[rr][1] = sigma2[off + row];
     Repoch[rr] = EP ? (double)epoch_of[off + row] : -2.0;
+  }
+  // ECORR couples a row only to the columns of its own epoch.  epoch_first[i] = the smallest TOA index (inside the pulsar) that shares TOA
+  // i's epoch: a step whose rows all have epoch_first > the wave's last column cannot meet an epoch partner there and skips the sixteen
+  // comparisons and conditional adds of its epilogue (with time-ordered TOAs that is every step off the diagonal; unsorted TOAs simply
+  // keep the arithmetic where a partner may lie).  NULL: every step keeps it.
+  if (EP && t < seg_rows / 16) {
+    int m = 0;
+    if (epoch_first) {
+      m = 0x7fffffff;
+      for (int j = 0; j < 16; ++j) {
+        const int row = rbeg + 16 * t + j;
+        if (row < N) m = min(m, epoch_first[off + row]);
+      }
+    }
+    Rlo16[t] = m;
   }
   __syncthreads();
   if (c0 >= N) return;                      // no barrier below: a wave may leave alone
@@ -391,6 +407,8 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   }
   auto step = [&](const int r0, double (&a)[NKS]) {  // 16 rows x COLS columns; r0 wave-uniform; `a` = the register set holding this step's fragments
     const bool diag_step = r0 < c0 + COLS;
+    int lo16 = 0;
+    if (EP && !diag_step) lo16 = Rlo16[(r0 - rbeg) >> 4];         // (requested here, used behind the products)
     const uint32_t xn = (uint32_t)min(r0 + 16 * DIST + li, N - 1);  // the rows this set serves next (past the segment: clamped, unused)
     pta_f64x4 acc[NT];
 #pragma unroll
@@ -405,7 +423,10 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
       if (DIAG != 2 && DIAG != 5) a[ks] = f_at(ks, xn);  // the fragment of the step DIST ahead into the register just consumed
       __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the loads behind the twelfth group of products)
     }
-    if (DIAG == 4 || DIAG == 5) {  // no epilogue at all: the products (and, 4, their fragment loads) alone
+    if (DIAG == 6) {  // the epilogue as a pure delay of its own length (~600 cycles): is a wave's gap filled by the SIMD's other wave?
+      __builtin_amdgcn_s_sleep(9);
+    }
+    if (DIAG == 4 || DIAG == 5 || DIAG == 6) {  // no epilogue at all: the products (and, 4, their fragment loads) alone
       double sacc = 0.0;
 #pragma unroll
       for (int jt = 0; jt < NT; ++jt) sacc += acc[jt][0] + acc[jt][1] + acc[jt][2] + acc[jt][3];
@@ -413,7 +434,20 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
       return;
     }
     // epilogue: white / ECORR terms added in the accumulators' own layout, then 16-byte stores (see the B operand above)
-    if (!diag_step && r0 + 16 <= N) {  // wave-uniform: strictly below the diagonal block, all 16 rows exist - nothing is predicated
+    if (!diag_step && r0 + 16 <= N && (!EP || __builtin_amdgcn_readfirstlane(lo16) >= c0 + COLS)) {
+      // wave-uniform: strictly below the diagonal block, all 16 rows exist, no row has an epoch partner among the wave's columns: the
+      // accumulators ARE the result
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        double *__restrict__ dst = C + (int64_t)(r0 + lq + 4 * reg) * ldc + scol0;
+#pragma unroll
+        for (int pp = 0; pp < NT / 2; ++pp) {
+          const f64x2 v = {acc[2 * pp][reg], acc[2 * pp + 1][reg]};
+          if (DIAG != 1) *reinterpret_cast<f64x2 *>(dst + 32 * pp) = v;
+          else if (v.x == 1.2345e300) C[0] = v.y;
+        }
+      }
+    } else if (!diag_step && r0 + 16 <= N) {  // the same with the ECORR term (nothing is predicated)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = r0 + lq + 4 * reg;
@@ -482,14 +516,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
 // two register sets does not fit 256 registers (35 spilled).
 static inline int pta_tcw_variant(int v, int K) { (void)v; (void)K; return 1; }
 static inline int pta_tcw_wgcols(int v, int K) { (void)v; (void)K; return 256; }
-static inline int pta_tcw_seg(int v) { return v == 2 ? 1024 : 512; }  // rows per work item (A/B: variant 2 = 1024)
+static inline int pta_tcw_seg(int v) { (void)v; return 512; }  // rows per work item (measured: 256 -> same, 1024 -> 3 % slower)
 
 // number of work items of the column-walking kernel per block and in all: item0[b] = first item of block b, item0[n_blocks] = total
 extern "C" int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host) {
 #ifdef PTA_TCW_DIAG
   variant &= 15;
 #endif
-  if (!blk_n_host || !item0_host || n_blocks <= 0 || variant < 0 || variant > 2) return -1;
+  if (!blk_n_host || !item0_host || n_blocks <= 0 || variant < 0 || variant > 1) return -1;
   const int wgc = pta_tcw_wgcols(variant, K), seg = pta_tcw_seg(variant);
   int64_t tot = 0;
   for (int b = 0; b < n_blocks; ++b) {
@@ -507,7 +541,7 @@ static int pta_td_cov_walk_nks(int K) { return K <= 0 || K > 64 ? 0 : (K > 56 &&
 extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                                         const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
                                         const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
-                                        const int32_t *item0, int64_t n_items, int variant, void *stream) {
+                                        const int32_t *item0, int64_t n_items, const int32_t *epoch_first, int variant, void *stream) {
   PTA_REQUIRE(Ft && phi && sigma2 && Cbase && blk_pos && blk_ld && blk_n && blk_off && item0, PTA_E_ARG, "pta_td_cov_assemble_walk: NULL argument");
   PTA_REQUIRE(!epoch_of || ecorr2, PTA_E_ARG, "pta_td_cov_assemble_walk: ecorr2 missing");
   PTA_REQUIRE(n_blocks > 0 && n_blocks <= 65535 && n_items > 0 && n_items < (1LL << 31), PTA_E_ARG, "pta_td_cov_assemble_walk: n_blocks=%d n_items=%lld",
@@ -517,14 +551,14 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   const int diag = variant >> 4;
   variant &= 15;
 #endif
-  PTA_REQUIRE(variant >= 0 && variant <= 2, PTA_E_ARG, "pta_td_cov_assemble_walk: variant=%d (0 .. 2)", variant);
+  PTA_REQUIRE(variant >= 0 && variant <= 1, PTA_E_ARG, "pta_td_cov_assemble_walk: variant=%d (0 or 1)", variant);
   const int nks = pta_td_cov_walk_nks(K);
   PTA_REQUIRE(nks > 0, PTA_E_ARG, "pta_td_cov_assemble_walk: needs 1 <= K <= 64 (K=%d): use pta_td_cov_assemble_all", K);
   PTA_REQUIRE(ldf > 0 && 64 * ldf < (1LL << 29), PTA_E_ARG, "pta_td_cov_assemble_walk: ldf=%lld too large for 32-bit operand offsets", (long long)ldf);
   const int v = pta_tcw_variant(variant, K);
 #define PTA_TCW_LAUNCH2(NKSV, EPV, NTV, DISTV)                                                                                              \
   hipLaunchKernelGGL((k_td_cov_walk<NKSV, EPV, NTV, DISTV>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, \
-                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant))
+                     epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant), epoch_first)
 #define PTA_TCW_LAUNCH1(NKSV, EPV) PTA_TCW_LAUNCH2(NKSV, EPV, 4, 1)
 #define PTA_TCW_LAUNCH(NKSV)      \
   if (epoch_of) {                 \
@@ -534,8 +568,8 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   }
 #ifdef PTA_TCW_DIAG
   if (diag && nks == 15 && epoch_of) {
-#define PTA_TCW_D(NTV, DISTV, DG) hipLaunchKernelGGL((k_td_cov_walk<15, true, NTV, DISTV, DG>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant))
-    { if (diag == 1) PTA_TCW_D(4, 1, 1); else if (diag == 2) PTA_TCW_D(4, 1, 2); else if (diag == 3) PTA_TCW_D(4, 1, 3); else if (diag == 4) PTA_TCW_D(4, 1, 4); else PTA_TCW_D(4, 1, 5); }
+#define PTA_TCW_D(NTV, DISTV, DG) hipLaunchKernelGGL((k_td_cov_walk<15, true, NTV, DISTV, DG>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant), epoch_first)
+    { if (diag == 1) PTA_TCW_D(4, 1, 1); else if (diag == 2) PTA_TCW_D(4, 1, 2); else if (diag == 3) PTA_TCW_D(4, 1, 3); else if (diag == 4) PTA_TCW_D(4, 1, 4); else if (diag == 5) PTA_TCW_D(4, 1, 5); else PTA_TCW_D(4, 1, 6); }
 #undef PTA_TCW_D
     PTA_LAUNCH_CHECK();
     return PTA_OK;

@@ -121,9 +121,21 @@ class TimeDomainMixin:
                 if total <= 0:
                     raise _lib.PtaError("pta_td_cov_walk_items failed")
                 items = self._td_walk_items = ((tuple(counts), K, variant), dv.i32(item0), total)
+            efirst = None
+            if ecorr2 is not None:   # per TOA: the first TOA (index inside the pulsar) of its ECORR epoch - where its epoch partners can begin
+                efirst = getattr(self, "_td_epoch_first", None)
+                if efirst is None or efirst[0] is not self.d_epoch_of:
+                    lo = np.empty(N, dtype=np.int32)
+                    for a in range(P):
+                        ep = np.asarray(self.epoch_of[a], dtype=np.int64)
+                        first = np.full(int(ep.max()) + 1 if len(ep) else 1, len(ep), dtype=np.int64)
+                        np.minimum.at(first, ep, np.arange(len(ep)))
+                        lo[self.off[a]:self.off[a + 1]] = first[ep]
+                    efirst = self._td_epoch_first = (self.d_epoch_of, dv.i32(lo))
             _lib.call("pta_td_cov_assemble_walk", dv.ptr(self.d_Ft), N, K, dv.ptr(phi), dv.ptr(self._td_sigma2),
                       dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
-                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, dv.ptr(items[1]), items[2], variant, s)
+                      dv.ptr(self.d_Ltd), *[dv.ptr(x) for x in self._td_layout], P, dv.ptr(items[1]), items[2],
+                      dv.ptr(efirst[1]) if efirst is not None else None, variant, s)
         elif kernel == "tile":
             _lib.call("pta_td_cov_assemble_all", dv.ptr(self.d_Ft) if K else None, N, K, dv.ptr(phi) if K else None, dv.ptr(self._td_sigma2),
                       dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,

@@ -15,7 +15,7 @@ eng, psrs, noise = bench.build_engine(68, 5000, seed=20260921)
 eng.prepare_td()
 counts = [int(c) for c in eng.counts]
 cov_bytes = 8.0 * sum(n * (n + 1) / 2 for n in counts)
-KERNELS = (("walk", "walk", 0), ("walk_seg1024", "walk", 2), ("tile", "tile", 0))
+KERNELS = (("walk", "walk", 0), ("tile", "tile", 0))
 for kname, kern, var in KERNELS:
     eng.td_cov_walk_variant = var
     eng.td_assemble(kernel=kern)

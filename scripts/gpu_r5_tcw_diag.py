@@ -12,7 +12,7 @@ eng, psrs, noise = bench.build_engine(68, 5000, seed=20260921)
 eng.prepare_td()
 res = {}
 for base, bname in ((1, "walk64"),):
-    for diag, dname in ((0, "full"), (1, "no_stores"), (2, "no_fragment_loads"), (3, "no_products"), (4, "products_and_loads_only"), (5, "products_only")):
+    for diag, dname in ((0, "full"), (1, "no_stores"), (2, "no_fragment_loads"), (3, "no_products"), (4, "products_and_loads_only"), (5, "products_only"), (6, "products_loads_and_a_600_cycle_sleep_per_step")):
         eng.td_cov_walk_variant = base + 16 * diag
         eng._td_walk_items = None
         eng.td_assemble(kernel="walk")
