@@ -449,7 +449,7 @@ typedef struct {
   const int32_t *gw_jlo;
   const double *gw_w;
   const double *det;          /* NULL = none */
-  const double *z;            /* ABI 3, rows_per_real == 1 only: NULL = every deviate is generated in registers (default); else the deviates
+  const double *z;            /* ABI 3 (ABI 7: also with rows_per_real > 1, row m = output row m): NULL = every deviate is generated in registers (default); else the deviates
                                  are READ: z[m * ld_z + blk_zoff[b] + j] = deviate j of row m for factor block b - what pta_rng_fill_normal
                                  (interleave = 1) writes for stream (stream_kind, b).  Same numbers either way, bit-identical output.
                                  A row must be READABLE up to blk_zoff[b] + blk_n[b] rounded up to a multiple of 4 (ld_z at least that);

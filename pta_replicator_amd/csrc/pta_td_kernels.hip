@@ -860,8 +860,8 @@ extern "C" int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint
   const int64_t nwg = p.n_items >= TDS_MANY_ITEMS ? (int64_t)((p.n_items + 7) / 8) * 8 * nmg : (int64_t)p.n_items * ((nmg + 7) / 8) * 8;
   PTA_REQUIRE(nwg < (1LL << 31), PTA_E_ARG, "pta_td_trmm_rng: %lld workgroups exceed one launch", (long long)nwg);
   if (p.z) {
-    PTA_REQUIRE(p.rows_per_real == 1 && p.ld_z >= 4 && p.blk_zoff, PTA_E_ARG,
-                "pta_td_trmm_rng: supplied deviates (plan.z) need rows_per_real == 1, blk_zoff and ld_z");
+    // (rows_per_real > 1 - the shared grid factor - reads row m of z for output row m = (realisation, pulsar): ld_z = one row's deviates)
+    PTA_REQUIRE(p.ld_z >= 4 && p.blk_zoff, PTA_E_ARG, "pta_td_trmm_rng: supplied deviates (plan.z) need blk_zoff and ld_z");
     // (measured and not kept: the same product as a 128 x 128-tile GEMM with BOTH operands by LDS DMA - the tile kernel of
     // pta_gemm.hip with a triangular K range, masked diagonal slabs and this epilogue, 4 x 4 fragments per wave instead of 1 x 16:
     // 28.8-29.0 ms per 1024 realisations of the 68 x 5000 array against 29.0 for this kernel - the DMA slab pipeline bounds both at

@@ -395,6 +395,7 @@ class ReplicaEngine(TimeDomainMixin):
         if grid_mode:
             self._prepare_gw_grid_factor()
             self.tdgw_plan.rng_fast = int(self.rng_fast)
+            self.tdgw_plan.z, self.tdgw_plan.ld_z, self.tdgw_plan.blk_zoff = None, 0, None   # (generate_td may have pointed it at a deviate buffer)
         s = dv.stream_ptr()
         for lo in range(0, R, step):
             n = min(step, R - lo)

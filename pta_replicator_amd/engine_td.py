@@ -252,6 +252,10 @@ class TimeDomainMixin:
         self.d_Lg, self.td_ldg = Lg, ldg
         gblk, gn0 = _strips([npts])
         self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0)]
+        # "memory" draws of the grid stage: one row of npts (rounded up to even) deviates per (realisation, pulsar), written by
+        # pta_rng_fill_normal_blocks as P blocks of a realisation's row - stream (TDGW, pulsar), the numbers the register form draws
+        self._tdgw_zld = (npts + 1) // 2 * 2
+        self._tdgw_fill = [dv.i32([npts] * P), dv.i32(np.arange(P) * self._tdgw_zld), dv.i32([0])]
         gp = _lib.TdPlan()
         gp.Lbase = Lg.data_ptr()
         gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0 = [x.data_ptr() for x in self._tdgw_keep]
@@ -294,11 +298,13 @@ class TimeDomainMixin:
         if bufs is None or len(bufs) < nbuf or bufs[0]["chunk"] < chunk or (zmem and bufs[0]["z"] is None):
             bufs = []
             for _ in range(nbuf):
-                b = {"chunk": chunk, "z": None, "G0": None, "G": None}
+                b = {"chunk": chunk, "z": None, "zg": None, "G0": None, "G": None}
                 if npts:
                     b["G0"], b["G"] = dv.empty((chunk, P, npts)), dv.empty((chunk, P, npts))
                 if zmem:
                     b["z"] = dv.zeros((chunk, zcols))
+                    if npts:   # the grid stage's deviates: [chunk * P, npts (even)] (+ a pad row for the product's 32-byte reads)
+                        b["zg"] = dv.zeros((chunk * P + 1, self._tdgw_zld))
                 bufs.append(b)
             self._td_bufs = bufs
             zoff = np.concatenate([[0], np.cumsum((self.counts + 1) // 2 * 2)]).astype(np.int64)   # every block starts on an even column
@@ -340,7 +346,15 @@ class TimeDomainMixin:
                     fill_chunk(b, lo, n, ctypes.c_void_p(fstream.cuda_stream))
                     self._td_fill_ev.record(fstream)
             if npts:
-                _lib.call("pta_td_trmm_rng", ctypes.byref(self.tdgw_plan), self.seed, r0 + lo, n * P, dv.ptr(b["G0"]), npts, sp)
+                gp = self.tdgw_plan
+                if zmem:   # grid deviates written once and READ by the product (as the per-pulsar part): the fp64 Box-Muller of the register
+                    # form shares the double-precision ALUs with the MFMAs (1.3 -> 0.8 ms per 1024 x 68 rows; bit-identical)
+                    _lib.call("pta_rng_fill_normal_blocks", self.seed, r0 + lo, n, STREAM_TDGW, P, dv.ptr(self._tdgw_fill[0]), dv.ptr(self._tdgw_fill[1]),
+                              npts, dv.ptr(b["zg"]), P * self._tdgw_zld, int(self.rng_fast), sp)
+                    gp.z, gp.ld_z, gp.blk_zoff = b["zg"].data_ptr(), self._tdgw_zld, self._tdgw_fill[2].data_ptr()
+                else:
+                    gp.z, gp.ld_z, gp.blk_zoff = None, 0, None
+                _lib.call("pta_td_trmm_rng", ctypes.byref(gp), self.seed, r0 + lo, n * P, dv.ptr(b["G0"]), npts, sp)
                 _lib.call("pta_gwb_mix", dv.ptr(self.d_M), P, dv.ptr(b["G0"]), n, npts, npts, dv.ptr(b["G"]), int(self.mix_variant), sp)
             if beside:
                 main.wait_event(self._td_fill_ev)
