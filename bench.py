@@ -109,14 +109,14 @@ def src_sha(*files):
     return h.hexdigest()[:16]
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 CZT_SRC = ("pta_czt_kernels.hip", "pta_fft.h", "pta_rng.h", "pta_rng_tables.h")
 
 
 def pmc_entry(key, srcs, **shape):
-    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r4.sh -> profiles/r04_pmc.json),
+    """counters of kernel `key` from the committed rocprofv3 --pmc passes (scripts/gpu_profile_r5.sh -> profiles/r05_pmc.json),
     or (None, reason) when the file is missing, was taken at another launch shape, or the kernel sources changed since."""
     try:
         with open(PMC_FILE) as fh:
@@ -366,7 +366,7 @@ def td_mode_numbers(eng, R):
     # MFMA-busy % from the committed PMC pass: the tile product over its dispatches of >= 1 ms (the trailing updates; the mean over all
     # of its launches, small ones included, is carried as ..._all_dispatches), the L.z product for the default (memory) form
     for key, name in (("k_dgemm_glds128", "potrf_trailing_update_mfma_busy_pct"), ("k_td_trmm_rng<false, true>", "trmm_mfma_busy_pct"),
-                      ("k_td_cov128", "cov_assemble_mfma_busy_pct")):
+                      ("k_td_cov_walk", "cov_assemble_mfma_busy_pct")):
         e, why = pmc_entry(key, TD_SRC, n_psr=eng.P)
         big = (e or {}).get("dispatches_over_1ms")
         res[name] = (big or e)["mfma_busy_pct"] if e else None
@@ -375,7 +375,7 @@ def td_mode_numbers(eng, R):
                 res[name + "_all_dispatches"] = e["mfma_busy_pct"]
                 res[name.replace("mfma_busy_pct", "gui_active_cycles_per_xcd_per_ns")] = big.get("gui_active_cycles_per_xcd_per_ns")   # NOT a clock (launch gaps)
             res[name + "_source"] = e.get("source")
-            if key == "k_td_cov128" and e.get("hbm_write_GBps"):   # counter bytes (WRITE_SIZE) over the rocprofv3 launch time
+            if key == "k_td_cov_walk" and e.get("hbm_write_GBps"):   # counter bytes (WRITE_SIZE) over the rocprofv3 launch time
                 res["cov_assemble_GBps_from_WRITE_SIZE"] = e["hbm_write_GBps"]
                 res["cov_assemble_write_bytes_pmc"] = e["write_kib_per_dispatch"] * 1024.0
         else:

@@ -94,8 +94,8 @@ def large_dispatches(match, min_ms=1.0):
     return {"dispatches": len(n), "min_ms": min_ms, "mfma_busy_pct": 100.0 * busy / (gui * SIMD_PER_XCD), "gui_active_cycles_per_xcd_per_ns": gui / 8 / (tot * 1e6)}
 
 
-for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_td_trmm_rng<false, false>", "k_td_cov128", "k_diag128", "k_trsm_mfma",
-          "k_potf2", "k_mb_mfma(", "k_mb_mfma_tile("):
+for k in ("k_dgemm_glds128", "k_td_trmm_rng", "k_td_trmm_rng<false, true>", "k_td_trmm_rng<false, false>", "k_td_cov128", "k_td_cov_walk", "k_diag128",
+          "k_trsm_mfma", "k_potf2", "k_mb_mfma(", "k_mb_mfma_tile("):
     m, nm = sums("pmc_mfma", k)
     ms, nt = avg_ms(k)
     if nm and m.get("GRBM_GUI_ACTIVE"):
