@@ -687,6 +687,14 @@ def compact_line(full):
     flat["td_ragged_cov_TBps"] = r(g(td, "ragged", "cov_assemble_TBps"))
     flat["td_config2_potrf_frac"] = r(g(td, "config2_shape", "potrf_frac_of_fp64_mfma_peak"))
     flat["td_config2_realisations_per_s"] = r(g(td, "config2_shape", "realisations_per_s"), 1)
+    # what THIS box's matrix pipe and HBM deliver in the same run (boxes of the pool differ by several per cent: 71-78 TFLOP/s on the
+    # register-tile microbenchmark, 2.17-2.30 GHz under the VALU kernels), and the TD fractions against it
+    mb = full.get("microbench") or {}
+    flat["box_fp64_mfma_microbench_TFLOPs"] = r(mb.get("fp64_mfma_tile_tflops"), 2)
+    flat["box_hbm_write_microbench_TBps"] = r(mb.get("hbm_write_TBps"), 3)
+    if mb.get("fp64_mfma_tile_tflops"):
+        flat["td_potrf_frac_of_box_microbench"] = r((td.get("potrf_TFLOPs") or 0) / mb["fp64_mfma_tile_tflops"]) if td.get("potrf_TFLOPs") else None
+        flat["td_trmm_frac_of_box_microbench"] = r((td.get("trmm_useful_TFLOPs") or 0) / mb["fp64_mfma_tile_tflops"]) if td.get("trmm_useful_TFLOPs") else None
     cb = full.get("cpu_baseline") or {}
     cpu = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "value_without_ecorr", "host_cpus", "error") if k in cb}
     if cb.get("sample"):
