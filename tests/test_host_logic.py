@@ -581,3 +581,20 @@ def test_from_enterprise_adapter_reads_enterprise_style_arrays():
     del b.pos
     with pytest.raises(AttributeError):
         from_enterprise(b)
+
+
+def test_walk_assembly_item_table_matches_its_definition():
+    """pta_td_cov_walk_items (host side of the column-walking TD assembly kernel): work items = (pulsar, 256-column group, 512-row segment of
+    the rows from the group's first column down) - item0[b] = first item of pulsar b, item0[P] = total = what the launch's grid will be."""
+    import ctypes
+    from pta_replicator_amd import _lib
+    rng = np.random.default_rng(3)
+    for counts in ([5000] * 68, [1], [2, 255, 256, 257, 511, 512, 513, 1024, 35037], list(rng.integers(1, 40000, 42))):
+        n = np.ascontiguousarray(counts, dtype=np.int32)
+        item0 = np.zeros(len(n) + 1, dtype=np.int32)
+        for variant in (0, 1):
+            tot = _lib.lib.pta_td_cov_walk_items(ctypes.c_void_p(n.ctypes.data), len(n), 60, variant, ctypes.c_void_p(item0.ctypes.data))
+            want = [sum(-(-(int(c) - 256 * cb) // 512) for cb in range(-(-int(c) // 256))) for c in counts]
+            assert tot == sum(want) == item0[-1] and list(np.diff(item0)) == want
+    assert _lib.lib.pta_td_cov_walk_items(None, 3, 60, 0, ctypes.c_void_p(item0.ctypes.data)) == -1
+    assert _lib.lib.pta_td_cov_walk_items(ctypes.c_void_p(n.ctypes.data), len(n), 60, 7, ctypes.c_void_p(item0.ctypes.data)) == -1
