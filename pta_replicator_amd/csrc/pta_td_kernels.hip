@@ -285,18 +285,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM == 128 ?
 // hazard was involved.  Here every k index is clamped to K - 1 (finite data) before it forms an address, and the tests run the kernel
 // on an Ft that is a view into a NaN-filled slab.
 #define TCW_SEG_MAX 512    // rows per work item (1024 measured 3 % slower: profiles/r05_tcw_diag.txt)
-// NT = 16-column tiles a wave owns (4: 64 columns, two workgroups per CU, 226-240 VGPRs; 8: 128 columns, ONE workgroup per CU with the
-// whole 512-entry register file per wave - 1 KB row segments per store, half the fragment traffic per byte written).  DIST = how many
-// steps ahead the A fragments are requested (a ring of DIST register sets, each set reloading itself for the step DIST ahead as its
-// values are consumed).  Why DIST matters beyond latency: on gfx950 loads and stores share ONE counter (vmcnt) and complete out of
-// order with respect to each other, so the wait in front of a group of products can only be "at most as many operations outstanding as
-// there are YOUNGER LOADS" (15 DIST - 1) - outstanding stores count against that allowance.  With DIST = 1 about 9 of the 14 younger
-// loads are still in flight (an L2 hit takes ~9 groups of products), which leaves room for ~5 outstanding 1 KB stores per wave - 10 MB
-// over the chip, Little's law for ~3 TB/s at the ~3 us a store takes to be acknowledged under load: the 2.96 TB/s measured.  DIST = 2
-// triples the allowance.
+// NT = 16-column tiles a wave owns (4: 64 columns, two workgroups per CU, 248 of 256 VGPRs).  The A fragments are requested ONE step ahead,
+// each into the register just consumed.  (On gfx950 loads and stores share one counter, vmcnt, and complete out of order with respect to
+// each other, so the wait in front of a group of products can only be "at most as many operations outstanding as there are YOUNGER LOADS" -
+// 14 here - and outstanding stores count against that allowance.  A form with 128 columns per wave and the fragments two steps ahead (one
+// workgroup per CU, 506 registers, vmcnt(29)) measured 2.67 against 2.33 ms: a single wave per SIMD exposes every stall.)
 // DIAG (probe builds only, -DPTA_TCW_DIAG; results are WRONG by construction): 1 = no global stores, 2 = no fragment loads inside the
 // steps, 3 = no products - which of the three streams bounds the kernel (scripts/gpu_r5_tcw_diag.py)
-template <int NKS, bool EP, int NT, int DIST, int DIAG = 0>
+template <int NKS, bool EP, int NT, int DIAG = 0>
 __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const double *__restrict__ Ft, int64_t ldf, int K, const double *__restrict__ phi,
                                                         const double *__restrict__ sigma2, const int32_t *__restrict__ epoch_of,
                                                         const double *__restrict__ ecorr2, double *__restrict__ Cbase,
@@ -395,21 +391,17 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   typedef double f64x2 __attribute__((ext_vector_type(2)));
   const int rfirst = max(rbeg, c0);  // rows above the wave's own columns are not in the lower triangle (both multiples of 16)
   if (rfirst >= rend) return;
-  double a0[NKS], a1[NKS];  // (a1 unused - and optimised away - when DIST == 1)
+  double a[NKS];
   {
-    const uint32_t x = (uint32_t)min(rfirst + li, N - 1), x1 = (uint32_t)min(rfirst + 16 + li, N - 1);
+    const uint32_t x = (uint32_t)min(rfirst + li, N - 1);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) a0[ks] = f_at(ks, x);
-    if (DIST == 2) {
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) a1[ks] = f_at(ks, x1);
-    }
+    for (int ks = 0; ks < NKS; ++ks) a[ks] = f_at(ks, x);
   }
-  auto step = [&](const int r0, double (&a)[NKS]) {  // 16 rows x COLS columns; r0 wave-uniform; `a` = the register set holding this step's fragments
+  auto step = [&](const int r0) {  // 16 rows x COLS columns; r0 wave-uniform
     const bool diag_step = r0 < c0 + COLS;
     int lo16 = 0;
     if (EP && !diag_step) lo16 = Rlo16[(r0 - rbeg) >> 4];         // (requested here, used behind the products)
-    const uint32_t xn = (uint32_t)min(r0 + 16 * DIST + li, N - 1);  // the rows this set serves next (past the segment: clamped, unused)
+    const uint32_t xn = (uint32_t)min(r0 + 16 + li, N - 1);  // the next step's rows (past the segment: clamped, unused)
     pta_f64x4 acc[NT];
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) acc[jt] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
@@ -420,7 +412,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
         if (DIAG == 3) acc[jt][ks & 3] = fma(a[ks], b[jt][ks], acc[jt][ks & 3]);
         else acc[jt] = pta_mfma_f64(a[ks], b[jt][ks], acc[jt]);
       }
-      if (DIAG != 2 && DIAG != 5) a[ks] = f_at(ks, xn);  // the fragment of the step DIST ahead into the register just consumed
+      if (DIAG != 2 && DIAG != 5) a[ks] = f_at(ks, xn);  // the next step's fragment into the register just consumed
       __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler gathers the loads behind the twelfth group of products)
     }
     if (DIAG == 6) {  // the epilogue as a pure delay of its own length (~600 cycles): is a wave's gap filled by the SIMD's other wave?
@@ -493,25 +485,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
       }
     }
   };
-  // first step(s) peeled: inside the loop the wait in front of a group of products then counts the fragment loads behind the one it
-  // needs as YOUNGER operations; merged with the kernel's prologue it would be stricter
-  step(rfirst, a0);
-  if constexpr (DIST == 2) {
-    // steps ALWAYS in pairs (one per register set), no conditional step: every wait inside the loop then sees the same 29 younger loads.
-    // rfirst and a full segment's end are multiples of 32, so only a pulsar's LAST segment can end on an odd step - its extra step lies
-    // wholly at rows >= N: operands clamped, every store predicated off
-    step(rfirst + 16, a1);
-    for (int r0 = rfirst + 32; r0 < rend; r0 += 32) {
-      step(r0, a0);
-      step(r0 + 16, a1);
-    }
-  } else {
-    for (int r0 = rfirst + 16; r0 < rend; r0 += 16) step(r0, a0);
-  }
+  // first step peeled: inside the loop the wait in front of a group of products then counts the fragment loads behind the one it needs as
+  // YOUNGER operations; merged with the kernel's prologue it would be stricter
+  step(rfirst);
+  for (int r0 = rfirst + 16; r0 < rend; r0 += 16) step(r0);
 }
 
 // variant of the column-walking kernel: 0 / 1 = 64 columns per wave, two workgroups per CU, fragments one step ahead (the only form built).
-// Measured and not kept (profiles/r05_tcw_variants.txt): 128 columns per wave with fragments two steps ahead (NT = 8, DIST = 2: one
+// Measured and not kept (profiles/r05_tcw_diag.txt): 128 columns per wave with fragments two steps ahead (one
 // workgroup per CU, 506 registers, vmcnt(29) waits) - 2.67 against 2.33 ms, a single wave per SIMD exposes every stall; 64 columns with
 // two register sets does not fit 256 registers (35 spilled).
 static inline int pta_tcw_variant(int v, int K) { (void)v; (void)K; return 1; }
@@ -556,10 +537,10 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   PTA_REQUIRE(nks > 0, PTA_E_ARG, "pta_td_cov_assemble_walk: needs 1 <= K <= 64 (K=%d): use pta_td_cov_assemble_all", K);
   PTA_REQUIRE(ldf > 0 && 64 * ldf < (1LL << 29), PTA_E_ARG, "pta_td_cov_assemble_walk: ldf=%lld too large for 32-bit operand offsets", (long long)ldf);
   const int v = pta_tcw_variant(variant, K);
-#define PTA_TCW_LAUNCH2(NKSV, EPV, NTV, DISTV)                                                                                              \
-  hipLaunchKernelGGL((k_td_cov_walk<NKSV, EPV, NTV, DISTV>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, \
+#define PTA_TCW_LAUNCH2(NKSV, EPV, NTV)                                                                                              \
+  hipLaunchKernelGGL((k_td_cov_walk<NKSV, EPV, NTV>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, \
                      epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant), epoch_first)
-#define PTA_TCW_LAUNCH1(NKSV, EPV) PTA_TCW_LAUNCH2(NKSV, EPV, 4, 1)
+#define PTA_TCW_LAUNCH1(NKSV, EPV) PTA_TCW_LAUNCH2(NKSV, EPV, 4)
 #define PTA_TCW_LAUNCH(NKSV)      \
   if (epoch_of) {                 \
     PTA_TCW_LAUNCH1(NKSV, true);  \
@@ -568,8 +549,8 @@ extern "C" int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, co
   }
 #ifdef PTA_TCW_DIAG
   if (diag && nks == 15 && epoch_of) {
-#define PTA_TCW_D(NTV, DISTV, DG) hipLaunchKernelGGL((k_td_cov_walk<15, true, NTV, DISTV, DG>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant), epoch_first)
-    { if (diag == 1) PTA_TCW_D(4, 1, 1); else if (diag == 2) PTA_TCW_D(4, 1, 2); else if (diag == 3) PTA_TCW_D(4, 1, 3); else if (diag == 4) PTA_TCW_D(4, 1, 4); else if (diag == 5) PTA_TCW_D(4, 1, 5); else PTA_TCW_D(4, 1, 6); }
+#define PTA_TCW_D(NTV, DG) hipLaunchKernelGGL((k_td_cov_walk<15, true, NTV, DG>), dim3((unsigned)n_items), dim3(256), 0, pta_stream(stream), Ft, ldf, K, phi, sigma2, epoch_of, ecorr2, Cbase, blk_pos, blk_ld, blk_n, blk_off, item0, n_blocks, pta_tcw_seg(variant), epoch_first)
+    { if (diag == 1) PTA_TCW_D(4, 1); else if (diag == 2) PTA_TCW_D(4, 2); else if (diag == 3) PTA_TCW_D(4, 3); else if (diag == 4) PTA_TCW_D(4, 4); else if (diag == 5) PTA_TCW_D(4, 5); else PTA_TCW_D(4, 6); }
 #undef PTA_TCW_D
     PTA_LAUNCH_CHECK();
     return PTA_OK;
