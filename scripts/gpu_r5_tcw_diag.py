@@ -2,6 +2,7 @@
 runs k_td_cov_walk on the 68 x 5000 array with one of its three streams removed (results wrong by construction):
     full | no global stores | no fragment loads inside the steps | no products (one fma per former MFMA)
 for the 64-column (two workgroups per CU) and the 128-column (one per CU, two steps ahead) form.  -> profiles/r05_tcw_diag.txt
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DPTA_TCW_DIAG -shared -o scripts/probe_src/libpta_tcw_diag.so pta_replicator_amd/csrc/*.hip
     PTA_REPLICATOR_AMD_LIB=scripts/probe_src/libpta_tcw_diag.so python scripts/gpu_r5_tcw_diag.py"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -411,15 +411,16 @@ def _ragged_engine(components, sizes=(777, 90, 1025, 2601), jitter=True, seed=No
     return eng.prepare()
 
 
-@pytest.mark.parametrize("components,jitter", [(30, True), (32, True), (29, True), (29, False), (10, True), (2, True), (13, False)])
-def test_td_covariance_walk_kernel_equals_the_tile_kernel_inside_a_nan_slab(components, jitter):
+@pytest.mark.parametrize("components,jitter,sizes", [(30, True, None), (32, True, None), (29, True, None), (29, False, None), (10, True, None), (2, True, None),
+                                                     (13, False, None), (30, True, (2, 3, 17, 64, 65, 255, 256, 257, 511, 513))])
+def test_td_covariance_walk_kernel_equals_the_tile_kernel_inside_a_nan_slab(components, jitter, sizes):
     """pta_td_cov_assemble_walk (a wave keeps the phi-scaled operand of its 64 columns in registers and walks down the rows) against
     pta_td_cov_assemble_all (64 x 128 tiles through LDS), K = 60 / 64 / 58 / 20 / 4 / 26: whole, cut and missing k-steps, with and without
     ECORR.  The design matrix is a VIEW into a slab that is NaN in front of and behind it - round 4's withdrawn kernel read rows k >= K behind
     the matrix and multiplied them by zero (0 x NaN = NaN: scripts/gpu_r5_nan_repro.py); any such read shows up here.  The lower
     triangles agree to rounding (phi enters on the other operand) and nothing outside them is written."""
     import torch
-    eng = _ragged_engine(components, jitter=jitter)
+    eng = _ragged_engine(components, jitter=jitter) if sizes is None else _ragged_engine(components, sizes=sizes, jitter=jitter)   # orders around every tile / group / segment boundary
     K, N = eng.plan.rn_k, eng.n_toa
     slab = torch.full((4 * N + K * N + 4 * N,), float("nan"), dtype=torch.float64, device="cuda")
     slab[4 * N:4 * N + K * N] = eng.d_Ft.reshape(-1)
