@@ -359,12 +359,14 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   // k rows of this lane: 4 ks + lq.  EVERY k is clamped to K - 1 BEFORE it forms an address (finite data meets b = 0; K <= 4 NKS, and a
   // small K may leave whole k-steps past it).  A k-step that lies wholly inside K takes a wave-uniform base (SGPRs) + the lane's 32-bit
   // element offset lq ldf + x (the host checks 64 ldf < 2^29): no 64-bit per-lane pointers in registers, one offset per step for all k-steps.
-  const uint32_t lqo = (uint32_t)lq * (uint32_t)ldf;
+  // (addresses = wave-uniform base + 32-bit per-lane BYTE offset: the form global_load / global_store take with a scalar base register,
+  // no 64-bit address arithmetic on the vector ALU inside the walk)
+  const uint32_t lqo = (uint32_t)lq * (uint32_t)ldf * 8u;
   auto f_at = [&](int ks, uint32_t x) -> double {  // F[min(4 ks + lq, K - 1), x]
     const bool whole = 4 * ks + 3 < K;             // kernel-uniform
-    const double *__restrict__ base = whole ? F + (int64_t)(4 * ks) * ldf : F;
-    const uint32_t o = whole ? lqo : (uint32_t)min(4 * ks + lq, K - 1) * (uint32_t)ldf;
-    return base[o + x];
+    const char *__restrict__ base = reinterpret_cast<const char *>(whole ? F + (int64_t)(4 * ks) * ldf : F);
+    const uint32_t o = whole ? lqo : (uint32_t)min(4 * ks + lq, K - 1) * (uint32_t)ldf * 8u;
+    return *reinterpret_cast<const double *>(base + (o + 8u * x));
   };
   // resident B operand: lane holds B[k = 4 ks + lq][j = li] = phi_k F[k, col(jt, li)]; k >= K enters as zero.  The sixteen columns of MFMA
   // tile jt are NOT sixteen neighbours: col(jt, li) = c0 + 32 (jt >> 1) + 2 li + (jt & 1) - tiles 2 p and 2 p + 1 interleave, so that a lane's
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
   }
   // store side: lane (lq, li) -> rows lq + 4 reg of a step, columns c0 + 32 p + 2 li, + 1 for p < NT / 2
   const int scol0 = c0 + 2 * li;
+  const uint32_t sto = ((uint32_t)lq * (uint32_t)ldc + (uint32_t)scol0) * 8u;  // byte offset of the lane's first column in row r0 + lq from row r0's start
   double ec[NT / 2][2];  // epochs of the lane's columns, as doubles (int32 -> double is exact); -1 past the block
 #pragma unroll
   for (int pp = 0; pp < NT / 2; ++pp)
@@ -431,11 +434,11 @@ __global__ __launch_bounds__(256, NT == 4 ? 2 : 1) void k_td_cov_walk(const doub
       // accumulators ARE the result
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        double *__restrict__ dst = C + (int64_t)(r0 + lq + 4 * reg) * ldc + scol0;
+        char *__restrict__ rowb = reinterpret_cast<char *>(C + (int64_t)(r0 + 4 * reg) * ldc);  // wave-uniform
 #pragma unroll
         for (int pp = 0; pp < NT / 2; ++pp) {
           const f64x2 v = {acc[2 * pp][reg], acc[2 * pp + 1][reg]};
-          if (DIAG != 1) *reinterpret_cast<f64x2 *>(dst + 32 * pp) = v;
+          if (DIAG != 1) *reinterpret_cast<f64x2 *>(rowb + (sto + 256u * pp)) = v;
           else if (v.x == 1.2345e300) C[0] = v.y;
         }
       }
