@@ -9,8 +9,8 @@ for p in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(p)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # one factorisation = the dispatches between two hipMemset-of-info markers is not visible here; take the run of potrf kernels that
-# follows the LAST k_td_cov128 launch (td_assemble) of the trace
-cov = [i for i, r in enumerate(rows) if "k_td_cov128" in r["Kernel_Name"]]
+# follows the LAST assembly launch (td_assemble: k_td_cov_walk / k_td_cov128) of the trace
+cov = [i for i, r in enumerate(rows) if "k_td_cov" in r["Kernel_Name"]]   # either assembly kernel (walking / tile)
 names = ("k_diag128", "k_ws_strips", "k_dgemm_glds128", "k_dgemm_mfma<", "k_potf2", "k_trsm", "k_syrk64", "k_inv_blocks")
 if not cov:
     sys.exit("no assembly launch found in the trace")
@@ -19,7 +19,7 @@ seg = []
 for r in rows[pick + 1:]:
     if any(n in r["Kernel_Name"] for n in names):
         seg.append(r)
-    elif seg and "k_td_cov128" in r["Kernel_Name"]:
+    elif seg and "k_td_cov" in r["Kernel_Name"]:
         break
 if not seg:
     sys.exit("no factorisation kernels after the last assembly")
