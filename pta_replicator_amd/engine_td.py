@@ -323,9 +323,10 @@ class TimeDomainMixin:
         los = list(range(0, R, chunk))
 
         # the deviate fill (VALU + stores) and the GWB grid stage (a small MFMA product + the ORF mix) of a chunk are independent: the fill
-        # can go to a second stream and be joined in front of the product (td_fill_beside_gwb, opt-in; same kernels, same counters;
-        # measured 31.26 against 31.27 ms per 1024 realisations of the 68 x 5000 array: nothing to gain, off by default)
-        beside = zmem and bool(npts) and not overlap and bool(getattr(self, "td_fill_beside_gwb", False))
+        # goes to a second stream and is joined in front of the product (td_fill_beside_gwb, default on; same kernels, same counters,
+        # bit-identical).  Round 4 measured nothing to gain (31.26 against 31.27 ms: the grid stage then drew in registers - VALU work like
+        # the fill); with the grid deviates read from memory it is MFMA work beside a VALU + store kernel: 29.95 against 30.05-30.2 ms
+        beside = zmem and bool(npts) and not overlap and bool(getattr(self, "td_fill_beside_gwb", True))
         if beside:
             fstream = getattr(self, "_td_fill_stream", None)
             if fstream is None:

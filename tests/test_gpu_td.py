@@ -386,7 +386,9 @@ def test_td_draws_from_memory_equal_draws_in_registers():
         assert torch.equal(eng.generate_td(70, r0=5), ref)
     eng.td_overlap = False
     assert torch.equal(eng.generate_td(70, r0=5), ref)
-    eng.td_fill_beside_gwb = True         # opt-in: the deviate fill on a second stream beside the GWB grid stage
+    eng.td_fill_beside_gwb = False        # the deviate fill on the product's own stream instead of beside the GWB grid stage (default: beside)
+    assert torch.equal(eng.generate_td(70, r0=5), ref)
+    eng.td_fill_beside_gwb = True
     assert torch.equal(eng.generate_td(70, r0=5), ref)
 
 
