@@ -584,7 +584,7 @@ def grid_cell(P, N, td=True, seed=20260921, td_gb_limit=200.0):
                 o2 = dv.empty((Rt, ntot))
                 eng.generate_td(Rt, out=o2)
                 tg = _wall(lambda: eng.generate_td(Rt, out=o2), 2)
-                cell["td"] = {"factor_GB": gb, "schedule": eng.td_potrf_mode_used, "cov_assemble_ms": ta * 1e3, "cov_assemble_TBps_written": 8.0 * P * N * (N + 64) / 2 / ta / 1e12,
+                cell["td"] = {"factor_GB": gb, "schedule": eng.td_potrf_mode_used, "cov_assemble_ms": ta * 1e3, "cov_assemble_kernel": getattr(eng, "td_cov_kernel_used", None), "cov_assemble_TBps_written": 8.0 * P * N * (N + 1) / 2 / ta / 1e12,
                               "potrf_ms": tf * 1e3, "potrf_TFLOPs": flop / tf / 1e12, "potrf_frac": flop / tf / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                               "generate_td_realisations": Rt, "generate_td_ms": tg * 1e3, "realisations_per_s": Rt / tg,
                               "trmm_useful_TFLOPs": P * float(N) ** 2 * Rt / tg / 1e12, "trmm_frac": P * float(N) ** 2 * Rt / tg / 1e12 / FP64_MFMA_PEAK_TFLOPS,
