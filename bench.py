@@ -1093,10 +1093,10 @@ def main():
         line.update(multi)
     if td is not None:
         line["td_mode"] = td
-        c5 = os.path.join(ROOT, "profiles", "r04_config5_td_mode.json")   # BASELINE config 5 in TD mode (160 GB of factors): a committed
+        c5 = os.path.join(ROOT, "profiles", "r05_config5_td_mode.json")   # BASELINE config 5 in TD mode (160 GB of factors): a committed
         if os.path.exists(c5):                                            # measurement of scripts/gpu_config5_td.py, NOT re-run here
             try:
-                td["config5_committed_measurement"] = dict(json.load(open(c5)), source="profiles/r04_config5_td_mode.json (scripts/gpu_config5_td.py)")
+                td["config5_committed_measurement"] = dict(json.load(open(c5)), source="profiles/r05_config5_td_mode.json (scripts/gpu_config5_td.py)")
             except Exception as exc:
                 td["config5_committed_measurement"] = {"error": str(exc)}
     if cfg4 is not None:
