@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PTA_ABI_VERSION 7
+#define PTA_ABI_VERSION 8
 
 #define PTA_OK 0
 #define PTA_E_ARG (-1)     /* bad argument (sizes, NULL pointers, unsupported lmax ...) */
@@ -122,6 +122,13 @@ int pta_ecorr(const int32_t *epoch_of, const double *ecorr_epoch, int N, int E, 
 
 /* ---------------------------------------------------------------- ORF -------------- */
 /* locs[a*2+0] = phi (RA, rad), locs[a*2+1] = theta (colatitude, rad) (red_noise.py:205-223). */
+
+/* HOST helper (ABI 8) of the ORF set-up: arg_host[a*P+b] = sin(theta_a) sin(theta_b) cos(phi_a - phi_b) + cos(theta_a) cos(theta_b), the
+ * argument of calczeta's arccos (spharmORFbasis.py:24), evaluated left to right through libm's scalar sin / cos like the reference's
+ * per-pair loop (spharmORFbasis.py:400-408) - in C++ instead of 20 100 Python-level iterations at 200 pulsars (61 ms -> < 1 ms).
+ * same_host[a*P+b] = 1 where both coordinates are identical (the exact-equality branch :23).  Symmetric [P, P] host arrays.
+ * arccos / cos of the result stay with NumPy (its float64 arccos is not libm's on AVX512 hosts): spharmORFbasis.pair_zeta_cos. */
+int pta_orf_pair_arguments(const double *locs_host, int P, double *arg_host, uint8_t *same_host);
 
 /* lmax = 0, clm = [sqrt(4 pi)] fast path: orf[a*P+b] = 2*HD(zeta_ab), 2 on zeta == 0.
  * Equals red_noise.py:224-226 with the defaults.                                           */

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "pta_pow_host": (c_int, [_P, c_double, c_int64, _P]),
     "pta_legacy_randn": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, c_int]),
     "pta_ecorr": (c_int, [_P, _P, c_int, c_int, _P, c_int64, c_int, _P, c_int64, c_int, _P]),
+    "pta_orf_pair_arguments": (c_int, [_P, c_int, _P, _P]),
     "pta_orf_hd": (c_int, [_P, c_int, _P, _P]),
     "pta_orf_basis": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "pta_orf_combine": (c_int, [_P, _P, c_int, c_int, _P, _P]),
@@ -143,7 +144,7 @@ for _name, (_res, _args) in _SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.pta_abi_version() != 7:
+if lib.pta_abi_version() != 8:
     raise ImportError("libpta_replicator_amd.so has an unexpected ABI version: rebuild it")
 
 

@@ -91,6 +91,37 @@ extern "C" int pta_pow_host(const double *x_host, double y, int64_t n, double *o
   return PTA_OK;
 }
 
+// HOST helper of the ORF set-up: the cosine of the pair separation as spharmORFbasis.py:24 writes it,
+//   argument = sin(theta1) * sin(theta2) * cos(phi1 - phi2) + cos(theta1) * cos(theta2)      (left to right, no contraction),
+// for every pair a <= b through libm's scalar sin / cos - what the reference's per-pair calczeta() evaluates on NumPy float64 scalars
+// (NumPy routes float64 sin / cos to libm; its arccos may not be libm's - AVX512 builds use SVML - so zeta = arccos(argument) and
+// cos(zeta) stay with NumPy on the host side: spharmORFbasis.pair_zeta_cos).  same[a*P+b] = 1 where the two positions are identical
+// (the reference's exact-equality branch, :23: zeta = 0 whatever the arithmetic would give).  Both outputs are symmetric [P, P].
+extern "C" int pta_orf_pair_arguments(const double *locs_host, int P, double *arg_host, uint8_t *same_host) {
+  PTA_REQUIRE(locs_host && arg_host && same_host, PTA_E_ARG, "pta_orf_pair_arguments: NULL argument");
+  PTA_REQUIRE(P > 0 && P <= 46340, PTA_E_ARG, "pta_orf_pair_arguments: P=%d", P);
+  std::vector<double> st(P), ct(P);
+  for (int a = 0; a < P; ++a) {
+    st[a] = sin(locs_host[2 * a + 1]);
+    ct[a] = cos(locs_host[2 * a + 1]);
+  }
+  for (int a = 0; a < P; ++a) {
+    const double p1 = locs_host[2 * a], t1 = locs_host[2 * a + 1];
+    for (int b = a; b < P; ++b) {
+      const double p2 = locs_host[2 * b], t2 = locs_host[2 * b + 1];
+      const double s12 = st[a] * st[b];
+      const double c12 = cos(p1 - p2);
+      const double left = s12 * c12;
+      const double right = ct[a] * ct[b];
+      const double arg = left + right;
+      const uint8_t same = (p1 == p2 && t1 == t2) ? 1 : 0;
+      arg_host[(int64_t)a * P + b] = arg_host[(int64_t)b * P + a] = arg;
+      same_host[(int64_t)a * P + b] = same_host[(int64_t)b * P + a] = same;
+    }
+  }
+  return PTA_OK;
+}
+
 // ---- NumPy's LEGACY normal stream, natively and on host threads (replay mode of the drop-in API) -------------------------------
 // The reference draws every deviate from the global np.random stream, re-seeded per call (white_noise.py:79-80,154-155,
 // red_noise.py:112-113): MT19937 seeded by init_genrand(seed), 53-bit doubles (a >> 5, b >> 6), Marsaglia's polar method with the

@@ -37,16 +37,62 @@ def calczeta(phi1, phi2, theta1, theta2):
     return float(np.arccos(argument))
 
 
-def pair_zeta_cos(psr_locs):
-    """[P, P, 2]: (zeta_ab, cos zeta_ab) for a <= b, evaluated pair by pair on NumPy float64 scalars like the reference's loop
-    (spharmORFbasis.py:400-408,166) - C libm underneath - so the ill-conditioned l >= 3 sums on the device start from the very
-    numbers the reference uses.  O(P^2) scalar work on the host (0.1 s at 200 pulsars), realisation independent."""
+def pair_zeta_cos_loop(psr_locs):
+    """[P, P, 2]: (zeta_ab, cos zeta_ab) for a <= b, pair by pair on NumPy float64 scalars exactly like the reference's loop
+    (spharmORFbasis.py:400-408,166).  The definition pair_zeta_cos is checked against - and its fallback; 61 ms at 200 pulsars."""
     P = len(psr_locs)
     zc = np.zeros((P, P, 2))
     for a in range(P):
         for b in range(a, P):
             z = calczeta(psr_locs[a][0], psr_locs[b][0], psr_locs[a][1], psr_locs[b][1])
             zc[a, b] = zc[b, a] = (z, np.cos(z))
+    return zc
+
+
+_PAIR_CHECK_SAMPLES = 48
+_native_pairs_ok = True     # cleared (once, with a warning) on a host where the native evaluation is not the scalar loop's bit for bit
+
+
+def pair_zeta_cos(psr_locs):
+    """[P, P, 2]: (zeta_ab, cos zeta_ab), the numbers the reference's per-pair loop produces (spharmORFbasis.py:14-35,400-408,166) -
+    the ill-conditioned l >= 3 sums on the device start from the very doubles the reference uses - without its 20 100 Python-level
+    iterations at 200 pulsars (61 ms of loop in front of 0.38 ms of kernel):
+
+    * the arccos argument of every pair comes from native host code (pta_orf_pair_arguments: libm sin / cos, the reference's
+      left-to-right association, no contraction) - NumPy routes float64 scalar sin / cos to the same libm;
+    * zeta = arccos(argument) and cos(zeta) are ONE NumPy call each over the pair array: NumPy's float64 arccos is NOT libm's on AVX512
+      hosts (SVML: 9 % of arguments differ by an ulp here), but its array loop is the inner loop its scalars go through;
+    * the reference's branches (identical positions -> 0, argument < -1 -> pi, > 1 -> 0) are applied on the arrays;
+    * every call re-derives a deterministic sample of pairs (all of them up to 48, the antipodal-most and closest included) with the
+      scalar loop and compares bit for bit; a host whose NumPy scalars do not route that way gets the loop for everything, with one warning.
+    """
+    global _native_pairs_ok
+    psr_locs = np.ascontiguousarray(psr_locs, dtype=np.float64)
+    P = len(psr_locs)
+    if not _native_pairs_ok or P == 0:
+        return pair_zeta_cos_loop(psr_locs)
+    arg = np.empty((P, P))
+    same = np.empty((P, P), dtype=np.uint8)
+    _lib.call("pta_orf_pair_arguments", dv.hptr(psr_locs), P, dv.hptr(arg), dv.hptr(same))
+    zeta = np.arccos(np.clip(arg, -1.0, 1.0))            # clip only guards the call: the branches below overwrite what it touched
+    zeta[arg < -1] = np.pi
+    zeta[arg > 1] = 0.0
+    zeta[same != 0] = 0.0
+    zc = np.stack([zeta, np.cos(zeta)], axis=2)
+    iu = np.triu_indices(P)
+    if len(iu[0]) > _PAIR_CHECK_SAMPLES:
+        order = np.argsort(arg[iu], kind="stable")
+        pick = np.unique(np.concatenate([order[:4], order[-4:], np.random.default_rng(P).choice(len(order), _PAIR_CHECK_SAMPLES - 8, replace=False)]))
+    else:
+        pick = np.arange(len(iu[0]))
+    for a, b in zip(iu[0][pick], iu[1][pick]):
+        z = calczeta(psr_locs[a][0], psr_locs[b][0], psr_locs[a][1], psr_locs[b][1])
+        if not (z == zc[a, b, 0] and np.cos(z) == zc[a, b, 1]):
+            import warnings
+            warnings.warn("pta_orf_pair_arguments does not reproduce NumPy's scalar sin / cos bit for bit on this host: the pair separations "
+                          "fall back to the per-pair Python loop", RuntimeWarning)
+            _native_pairs_ok = False
+            return pair_zeta_cos_loop(psr_locs)
     return zc
 
 

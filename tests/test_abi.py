@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_error_channel_without_gpu():
     from pta_replicator_amd import _lib
-    assert _lib.lib.pta_abi_version() == 7
+    assert _lib.lib.pta_abi_version() == 8
     rc = _lib.lib.pta_quantize_epochs(None, 0, 1.0, None, None, None, None)
     assert rc == -1 and "NULL" in _lib.last_error()
     with pytest.raises(_lib.PtaError):

@@ -544,6 +544,96 @@ def test_bench_ragged_workload_definition():
         assert {f["f"] for f in p.toas.flags} <= set(fl)
 
 
+def test_native_pair_separations_equal_the_scalar_loop_bit_for_bit():
+    """pair_zeta_cos (native arccos arguments + one NumPy arccos / cos over the pair array) against the per-pair scalar loop
+    the reference runs (spharmORFbasis.py:14-35,400-408) - array_equal on all 20 100 pairs of BASELINE config 5's geometry, on a geometry
+    with repeated positions (the exact-equality branch), near-antipodal and near-coincident pairs (arguments at and beyond +-1), and on
+    small arrays (every pair re-derived by the self-check); the fallback switch hands the loop's numbers back unchanged."""
+    import time
+    from pta_replicator_amd import spharmORFbasis as anis
+    rng = np.random.default_rng(200)
+    P = 200
+    raj, decj = rng.uniform(0, 24, P), np.degrees(np.arcsin(rng.uniform(-1, 1, P)))
+    locs = np.ascontiguousarray(np.stack([raj * np.pi / 12.0, np.pi / 2.0 - np.radians(decj)], axis=1))
+    t0 = time.perf_counter()
+    ref = anis.pair_zeta_cos_loop(locs)
+    t1 = time.perf_counter()
+    got = anis.pair_zeta_cos(locs)
+    t2 = time.perf_counter()
+    assert anis._native_pairs_ok
+    assert np.array_equal(ref, got)
+    assert (t2 - t1) < 0.5 * (t1 - t0)                      # 61 ms -> ~1.5 ms here (the sampled self-check included)
+    # repeated positions, antipodes, poles, nearly identical positions
+    sp = np.array([[1.0, 0.7], [1.0, 0.7], [1.0 + np.pi, np.pi - 0.7], [0.3, 0.0], [2.9, np.pi], [1.0, 0.7 + 1e-9], [1.0 + 1e-15, 0.7],
+                   [4.0, 1.5707963267948966], [4.0 - np.pi, 1.5707963267948966], [5.5, 1e-300]])
+    ref = anis.pair_zeta_cos_loop(sp)
+    got = anis.pair_zeta_cos(sp)
+    assert np.array_equal(ref, got)
+    assert got[0, 1, 0] == 0.0 and got[0, 1, 1] == 1.0 and abs(got[0, 2, 0] - np.pi) < 1e-7
+    for seed in range(5):
+        r2 = np.random.default_rng(seed)
+        q = np.stack([r2.uniform(0, 2 * np.pi, 7), np.arccos(r2.uniform(-1, 1, 7))], axis=1)
+        assert np.array_equal(anis.pair_zeta_cos_loop(q), anis.pair_zeta_cos(q))
+    anis._native_pairs_ok = False
+    try:
+        assert np.array_equal(anis.pair_zeta_cos(sp), ref)
+    finally:
+        anis._native_pairs_ok = True
+
+
+def test_bench_line_roofline_fits_the_driver_record():
+    """VERDICT r5 #1a: the driver's record keeps the first 24 keys of `roofline`, names cut at 40 characters, strings at 120 - two rounds of
+    TD-mode fractions (BASELINE.json's "fp64 Cholesky MFMA util %" half of the metric) were cut off behind longer lists.  compact_line on a
+    full record with EVERY source field present: <= 24 keys, every name <= 40 characters, the contract's eight first and in order, the TD
+    fractions inside the kept prefix, no string over 120 characters anywhere in the two flat objects; the line stays one JSON line."""
+    import json
+    import bench
+    long = "x" * 400
+    full = {"metric": "realizations/sec, 68 psr x 5000 TOAs GWB+RN+WN", "value": 2.1e5, "unit": "realizations/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+            "ms_per_step": 4.86, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": long, "realisations_per_step_per_gpu": 1024},
+            "roofline": {"kernel": "pta_engine_synth", "bound": "fp64-valu (rng)", "bound_by_contract_enum": "hbm", "achieved": 959.4, "peak": 8000.0, "unit": "GB/s",
+                         "frac": 0.1199, "traffic": 3.36e9, "avg_launch_ms": 2.9, "engine_clock_GHz": 2.3,
+                         "valu_issue": {"insts_valu_per_output_element": 219.3, "frac_of_launch_at_measured_clock": 0.7},
+                         "also": {"kernel": "pta_gwb_czt", "stage_ms": 2.07, "frac": 0.51}},
+            "step": {"frac_of_fp64_peak": 0.336, "normals_T_per_s": 0.296, "frac_of_rng_microbench": 0.49},
+            "microbench": {"fp64_mfma_tile_tflops": 72.3, "hbm_write_TBps": 4.37, "normals_T_per_s": 0.6},
+            "orf_config5": {"orf_basis_ms": 0.38, "orf_combine_ms": 0.005, "host_pair_separations_ms": 0.9, "host_pair_separations_python_loop_ms": 61.0},
+            "td_mode": {"cov_assemble_kernel": "walk", "cov_assemble_ms": 2.05, "cov_assemble_GBps_lower_triangle": 3323.0, "cov_assemble_walk_ms": 2.05,
+                        "cov_assemble_tile_ms": 2.95, "potrf_ms": 53.0, "potrf_TFLOPs": 53.4, "potrf_frac_of_fp64_mfma_peak": 0.68,
+                        "potrf_trailing_update_mfma_busy_pct": 83.8, "generate_td_ms": 30.07, "trmm_useful_TFLOPs": 57.9, "trmm_frac_of_fp64_mfma_peak": 0.737,
+                        "realisations_per_s": 34053.0, "prepare_td_first_call_ms": 244.3, "prepare_td_ms": 56.0,
+                        "ragged": {"potrf_TFLOPs": 62.2, "potrf_frac_of_fp64_mfma_peak": 0.792, "trmm_frac_of_fp64_mfma_peak": 0.798, "cov_assemble_TBps": 3.4},
+                        "config2_shape": {"potrf_frac_of_fp64_mfma_peak": 0.69, "realisations_per_s": 31500.0}},
+            "cpu_baseline": {"value": 0.34, "unit": "realisations/s", "cores": 1, "kind": "port", "sample": long, "value_without_ecorr": 3.66, "host_cpus": 256,
+                             "reference_container": {"value": 0.056, "value_without_ecorr": 0.71, "cores": 8, "date": "2026-09-30"}},
+            "grid": [{"n_psr": 3, "n_toa": 122, "throughput": {"realisations_per_s": 7.7e6}, "td": {"potrf_frac": 0.0, "trmm_frac": 0.0},
+                      "cpu": {"realisations_per_s": 55.0, "kind": "port", "cores": 1}}],
+            "kernels_ms": {"pta_engine_synth": 2.9}}
+    line = bench.compact_line(full)
+    roof = line["roofline"]
+    assert len(roof) <= 24 and bench.ROOFLINE_MAX_KEYS == 24
+    assert all(len(k) <= 40 for k in roof), [k for k in roof if len(k) > 40]
+    assert list(roof)[:8] == ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"]
+    for k in ("td_potrf_frac", "td_potrf_mfma_busy_pct", "td_trmm_frac", "td_cov_frac_hbm", "td_cov_TBps", "td_realisations_per_s", "td_ragged_potrf_frac",
+              "td_prepare_first_call_ms", "step_frac_of_fp64_peak", "valu_insts_per_out_elem", "box_fp64_mfma_TFLOPs", "box_hbm_write_TBps",
+              "orf_basis_ms_P200_lmax4", "frac_rng"):
+        assert roof[k] is not None, k
+    assert roof["bound"] == "fp64-valu (rng)" and roof["td_potrf_frac"] == 0.68 and roof["td_realisations_per_s"] == 34053.0
+    assert abs(roof["td_cov_frac_hbm"] - 3323.0 / 8000.0) < 1e-4
+    cpu = line["cpu_baseline"]
+    assert len(cpu) <= 12 and all(len(k) <= 40 for k in cpu)
+    assert cpu["reference_in_build_container"] == 0.056 and cpu["reference_date"] == "2026-09-30"
+    for obj in (roof, cpu, line["config"]):
+        assert all(len(v) <= 120 for v in obj.values() if isinstance(v, str))
+    assert line["grid"][0]["cpu_real_per_s"] == 55.0 and line["grid"][0]["cpu_kind"] == "port"
+    txt = json.dumps(line)
+    assert "\n" not in txt and len(txt) < 8000
+    # an empty record (N > 1 ranks carry no TD / microbench blocks) still yields the contract's keys
+    empty = bench.compact_line({"roofline": {"kernel": "k", "bound": "hbm"}})
+    assert list(empty["roofline"])[:8] == list(roof)[:8] and len(empty["roofline"]) <= 24
+
+
 def test_from_enterprise_adapter_reads_enterprise_style_arrays():
     """VERDICT r4 #6 / SURVEY.md §7 step 2: an object with enterprise's array surface (toas [s], toaerrs [s], flags dict, backend_flags,
     _raj/_decj or theta/phi or pos) becomes an array-backed SimulatedPulsar that the add_* functions and the engine take; the numbers the
