@@ -112,7 +112,7 @@ def src_sha(*files):
 PMC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{n}_pmc.json") for n in (6, 5)) if os.path.exists(p)),
                 os.path.join(ROOT, "profiles", "r06_pmc.json"))
 SYNTH_SRC = ("pta_engine_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
-TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_orf_kernels.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
+TD_SRC = ("pta_td_kernels.hip", "pta_gemm.hip", "pta_potrf.hip", "pta_rng.h", "pta_rng_tables.h", "pta_mfma.h")
 CZT_SRC = ("pta_czt_kernels.hip", "pta_fft.h", "pta_rng.h", "pta_rng_tables.h")
 
 

@@ -179,6 +179,11 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
 #define PTA_POTRF_LOCKSTEP 64       /* A/B (workspace scheme): all chains start together instead of one diagonal phase apart */
 #define PTA_POTRF_EPI1 0x100000     /* A/B: the 128 x 128-tile products prefetch their C tile behind the last slab and store interior tiles
                                        unpredicated (pta_dgemm algo 3; also honoured by pta_potrf_ragged_plan) */
+#define PTA_POTRF_LEFT 0x200000     /* workspace scheme (ABI 8), LEFT-LOOKING panel order: a finished panel is not applied to the trailing matrix;
+                                     * before a panel is factored its block column is updated once with everything to its left (one tile
+                                     * product of K = the panel's first column: a C tile is read and written once, not once per panel) */
+#define PTA_POTRF_LEFT_SPLIT 0x400000 /* with PTA_POTRF_LEFT: the part of that update that only needs panels <= q - 2 runs ahead on an internal
+                                       * side stream beside panel q - 1's diagonal phase and substitution */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 /* The same factorisation with a caller-owned workspace (device memory, `work_doubles` doubles, at least

@@ -44,7 +44,8 @@ bool rccl_bind(void *h, rccl_api &r) {
 int rccl_find_loaded(struct dl_phdr_info *info, size_t, void *data) {
   if (!info->dlpi_name || !rccl_basename_matches(info->dlpi_name)) return 0;
   void *h = dlopen(info->dlpi_name, RTLD_NOW | RTLD_NOLOAD);
-  if (h && rccl_bind(h, *(rccl_api *)data)) return 1;  // stop: bound
+  if (h && rccl_bind(h, *(rccl_api *)data)) return 1;  // stop: bound (the handle is kept for the life of the process)
+  if (h) dlclose(h);                                    // a rejected candidate: give back the reference RTLD_NOLOAD took
   return 0;                                             // not a usable RCCL: keep walking
 }
 
@@ -60,6 +61,7 @@ void rccl_load_once() {
       r.ok = true;
       return;
     }
+    if (h) dlclose(h);
   }
   r = rccl_api();
 }

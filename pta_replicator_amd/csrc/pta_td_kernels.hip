@@ -1,5 +1,5 @@
 // TD ("time-domain") mode: the dense path BASELINE.json's north_star describes - per-pulsar covariance
-// assembly, blocked fp64 Cholesky (pta_potrf_batched, pta_orf_kernels.hip) and L . Z.  The reference has no
+// assembly, blocked fp64 Cholesky (pta_potrf_batched, pta_potrf.hip) and L . Z.  The reference has no
 // such path; the covariance is the one implied by its RN/WN/ECORR synthesis (App. A.1):
 //   C[i,j] = sum_c phi[c] F[i,c] F[j,c] + (i==j) sigma2[i] + (epoch_i == epoch_j) ecorr2[i]
 // (red_noise.py:98-101,126-128; white_noise.py:105-109,182).

@@ -314,6 +314,11 @@ class ReplicaEngine(TimeDomainMixin):
                 torch.cuda.current_stream().synchronize()      # once, not once per pulsar per source
             pl.det = self.d_det.data_ptr()
         self._prepared = True
+        # set-up time is where one-off driver costs belong: with measurement noise configured the dense path can follow, and the
+        # factorisation's internal streams (hardware queues, ~10 ms each on this stack: profiles/r05_prepare_td_first_call.txt) are
+        # created now instead of inside the first prepare_td() (td_warmup = False leaves them to be created on demand)
+        if self._wn is not None and getattr(self, "td_warmup", True):
+            _lib.call("pta_potrf_warmup", 2)
         return self
 
     def psrs_ideal_view(self):

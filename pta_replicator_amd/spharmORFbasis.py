@@ -81,8 +81,9 @@ def pair_zeta_cos(psr_locs):
     zc = np.stack([zeta, np.cos(zeta)], axis=2)
     iu = np.triu_indices(P)
     if len(iu[0]) > _PAIR_CHECK_SAMPLES:
-        order = np.argsort(arg[iu], kind="stable")
-        pick = np.unique(np.concatenate([order[:4], order[-4:], np.random.default_rng(P).choice(len(order), _PAIR_CHECK_SAMPLES - 8, replace=False)]))
+        au = arg[iu]
+        ends = np.argpartition(au, (3, len(au) - 4))
+        pick = np.unique(np.concatenate([ends[:4], ends[-4:], np.random.default_rng(P).choice(len(au), _PAIR_CHECK_SAMPLES - 8, replace=False)]))
     else:
         pick = np.arange(len(iu[0]))
     for a, b in zip(iu[0][pick], iu[1][pick]):

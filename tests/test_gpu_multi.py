@@ -64,3 +64,32 @@ def test_c_abi_gather_single_rank_and_rccl_communicator():
         comm.destroy()
     with pytest.raises(_lib.PtaError):
         _lib.call("pta_gather_rank0", None, 0, 2, 0, dv.ptr(x), 14, 33, 33, dv.ptr(x), 33, dv.stream_ptr())   # two ranks need a communicator
+
+
+def test_bench_two_ranks_dry_run_on_one_device():
+    """bench.py's N > 1 branch (env handling, disjoint realisation ranges, barrier + max-over-ranks timing, the all_gather of
+    per-rank step times, the pipelined generate + gather to rank 0, ONE JSON line from rank 0, clean exit of every rank) was executed by
+    no test.  Launched exactly as the driver launches it - python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 - with the
+    two dry-run switches of bench.py (both ranks on cuda:0, gloo as the control plane: a 1-GPU box has no second device for RCCL) and a
+    batch small enough for gloo's ~50 MB/s device-tensor transport.  Claims nothing about scaling."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PTA_BENCH_SINGLE_DEVICE="1", PTA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "32", "--no-td", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 only, one line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "realizations/s"
+    assert d["rccl_ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert len(d["ms_per_step_per_rank"]) == 2 and all(t > 0 for t in d["ms_per_step_per_rank"])
+    # value = the realisations ALL ranks generated over the max-over-ranks time
+    assert abs(d["value"] - 2 * 32 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    g = d["gathered_to_rank0"]
+    assert "error" not in g, g
+    assert g["realisations"] == 64 and g["realisations_per_s"] > 0
+    assert d["config"]["parallelism"] == "replica-shard x2"
+    roof = d["roofline"]
+    assert len(roof) <= 24 and all(len(k) <= 40 for k in roof) and roof["kernel"] and roof["frac"] > 0
