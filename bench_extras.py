@@ -135,25 +135,31 @@ def td_mode_numbers(eng, R):
         # the schedule prepare_td() uses (workspace scheme, next panel's diagonal phase run ahead) and the workspace-free two-chain one
         need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, _lib.POTRF_DIAG_AHEAD))
         work = dv.empty((need,))
-        ts, ts_free, bad = [], [], 0
+        ts_free, bad = [], 0
         for _ in range(2):
             wall(assemble)
             ts_free.append(wall(lambda: _lib.call("pta_potrf_batched_ex", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), 0, s)))
             bad += int(info.abs().sum().item())
-        ts_epi = []
-        for _ in range(4):
-            ta = wall(assemble)
-            ts.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD,
-                                             dv.ptr(work), need, s)))
-            bad += int(info.abs().sum().item())
-            wall(assemble)   # A/B: the tile products' C-tile prefetch epilogue (PTA_POTRF_EPI1)
-            ts_epi.append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD | _lib.POTRF_EPI1,
-                                                 dv.ptr(work), need, s)))
-            bad += int(info.abs().sum().item())
-        res["potrf_epi1_ms"] = min(ts_epi) * 1e3
+        # the panel orders of the workspace scheme, same kernels: left-looking (the engine's default since round 6), right-looking with the next
+        # panel's diagonal phase run ahead (rounds 3-5), and the A/B forms of each (left + run-ahead diagonal phases; the C-tile prefetch epilogue)
+        orders = {"left": _lib.POTRF_LEFT, "right": _lib.POTRF_DIAG_AHEAD, "left_diag_ahead": _lib.POTRF_LEFT | _lib.POTRF_DIAG_AHEAD,
+                  "right_epi1": _lib.POTRF_DIAG_AHEAD | _lib.POTRF_EPI1}
+        tord = {k: [] for k in orders}
+        for rep in range(4):
+            for k, fl in orders.items():
+                if rep >= 2 and k not in ("left", "right"):
+                    continue
+                ta = wall(assemble)
+                tord[k].append(wall(lambda: _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), fl, dv.ptr(work), need, s)))
+                bad += int(info.abs().sum().item())
+        res["potrf_left_looking_ms"] = min(tord["left"]) * 1e3
+        res["potrf_right_looking_ms"] = min(tord["right"]) * 1e3
+        res["potrf_left_diag_ahead_ms"] = min(tord["left_diag_ahead"]) * 1e3
+        res["potrf_epi1_ms"] = min(tord["right_epi1"]) * 1e3
+        res["potrf_schedule"] = getattr(eng, "td_potrf_order", "left") + "-looking panels, 2 chains (what prepare_td() runs)"
         info.add_(bad)
         del work
-        tp = min(ts)
+        tp = min(tord["left" if getattr(eng, "td_potrf_order", "left") == "left" else "right"])
         res.update({"potrf_workspace_GB": 8.0 * need / 1e9, "potrf_without_workspace_ms": min(ts_free) * 1e3})
         # the same batch through the END-ALIGNED ragged schedule (pta_potrf_ragged; a uniform batch is its special case front = const)
         try:
@@ -170,7 +176,7 @@ def td_mode_numbers(eng, R):
 
         def factor_loop():
             assemble()
-            _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_DIAG_AHEAD, dv.ptr(work2), need, s)
+            _lib.call("pta_potrf_batched_ws", dv.ptr(eng.d_Ltd), n, ld, n * ld, P, dv.ptr(info), _lib.POTRF_LEFT, dv.ptr(work2), need, s)
         work2 = dv.empty((need,))
         ck = engine_clock_during(factor_loop, 0.6)
         del work2

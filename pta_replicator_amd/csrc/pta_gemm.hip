@@ -366,11 +366,22 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_glds128(int M, int N, int K, d
                                                           int c0v, int kv0, int bws) {
   int bm = blockIdx.y, bn = blockIdx.x;
   if (lower_only == 2) {
+    // 1-D grid over the tiles on or below the diagonal of a TRAPEZOID (M >= N): the nt (nt + 1) / 2 tiles of the top square row by row,
+    // then the (mt - nt) x nt rectangle below it row by row.  Workgroups are dealt to the 8 XCDs round-robin, so every XCD gets the same
+    // number of tiles (a 2-D grid with early exits above the diagonal gives XCD x = column tile x its 31 - x tiles of a 31 x 8 block
+    // column: the first XCD carries 29 % more than the last - round 6, profiles/r06_potrf_left_looking.txt), and in the rectangle an XCD
+    // keeps ONE column tile (nt = 8), whose operand stays in its L2.
     const int tix = blockIdx.x;
-    bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-    while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
-    while (bm * (bm + 1) / 2 > tix) --bm;
-    bn = tix - bm * (bm + 1) / 2;
+    const int nt = (N + HBM_T - 1) / HBM_T, tri = nt * (nt + 1) / 2;
+    if (tix < tri) {
+      bm = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+      while ((bm + 1) * (bm + 2) / 2 <= tix) ++bm;
+      while (bm * (bm + 1) / 2 > tix) --bm;
+      bn = tix - bm * (bm + 1) / 2;
+    } else {
+      bm = nt + (tix - tri) / nt;
+      bn = (tix - tri) % nt;
+    }
   } else if (lower_only && bn * HBM_T > bm * HBM_T + (HBM_T - 1)) {
     return;
   }
@@ -615,6 +626,11 @@ int pta_dgemm_launch(int transB, int M, int N, int K, double alpha, const double
     }
     const bool vec = transB && ska == 1 && (K % 2) == 0 && (lda % 2) == 0 && (ldb % 2) == 0 && (sA % 2) == 0 && (sB % 2) == 0 &&
                      ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0;
+    if (lower_only == 1 && M > N && vec && algo >= 2) {  // trapezoid (a block column with its diagonal block on top): 1-D grid over its tiles
+      const unsigned nt = pta_cdiv(N, HBM_T), mt = pta_cdiv(M, HBM_T);
+      g = dim3(nt * (nt + 1) / 2 + (mt - nt) * nt, 1, batch);
+      lower_only = 2;
+    }
     if (vec && algo >= 2) {
       auto kern = algo == 3 ? k_dgemm_glds128<false, 1> : k_dgemm_glds128<false, 0>;
       hipLaunchKernelGGL(kern, g, dim3(256), 0, stream, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc,

@@ -2,6 +2,7 @@
 // covariances of TD mode.  Entry points: pta_potrf_batched / _ex / _ws (uniform batches), pta_potrf_ragged (+ _plan; matrices of
 // different orders as one end-aligned schedule), pta_potrf_workspace_doubles, pta_potrf_warmup.  The tile products are pta_gemm.hip's.
 // (Moved out of pta_orf_kernels.hip in round 6, unchanged.)
+#include <stdlib.h>
 #include "pta_common.h"
 #include "pta_mfma.h"
 
@@ -298,7 +299,16 @@ static int pta_potrf_ctx_get(pta_potrf_ctx **out, int nchain = PTA_POTRF_MAX_CHA
     hipStream_t st[2] = {nullptr, nullptr};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipSuccess;
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking);
+    // st[0] = the chain's stream, st[1] = its look-ahead stream.  PTA_POTRF_SIDE_PRIO=1 in the environment creates the look-ahead stream at
+    // the device's highest queue priority (A/B of round 6, measured and NOT the default: a diagonal phase dispatched ahead of the tile
+    // products' workgroups still runs several times slower beside them and now delays them too - 68 x 5000^2 right-looking 52.6 against
+    // 52.3 ms, 16 x 10 000^2 98.0 against 94.1, left-looking with run-ahead diagonal phases 54.6 against 51.4: profiles/r06_potrf_left_looking.txt)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);   // (least, greatest): numerically lower = higher priority
+    const char *pe = getenv("PTA_POTRF_SIDE_PRIO");
+    const bool side_hi = pe && pe[0] == '1';
+    e = hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking);
+    if (e == hipSuccess) e = side_hi ? hipStreamCreateWithPriority(&st[1], hipStreamNonBlocking, prio_hi) : hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking);
     for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
     if (e != hipSuccess) {
       for (int k = 0; k < 2; ++k)
@@ -957,7 +967,37 @@ static int pta_potrf_chain_ws_left(double *A, int n, int64_t lda, int64_t stride
   const bool split = (flags & PTA_POTRF_LEFT_SPLIT) != 0 && side != nullptr;
   const int64_t ldw = pta_potrf_ws_ld(NBO);
   pta_ws_panel p = pta_ws_panel_at(n, NBO, 0);
-  int rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, s);
+  int rc;
+  if ((flags & PTA_POTRF_DIAG_AHEAD) && !split && side != nullptr) {
+    // PTA_POTRF_LEFT | PTA_POTRF_DIAG_AHEAD: every diagonal phase runs on the (high-priority) side stream.  The update of block column q is
+    // issued top first - U_top(q): the panel's own nbo x nbo diagonal block, a triangular grid - and diag(q) starts behind it, beside
+    // U_rest(q), the rectangle below (no tile is touched twice: top and rest are disjoint).  ev_solved here = "U_top done", ev_ua = "diag done".
+    hipEvent_t ev_top = ev_solved, ev_diag = ev_ua;
+    if (hipEventRecord(ev_top, s) != hipSuccess || hipStreamWaitEvent(side, ev_top, 0) != hipSuccess) return PTA_E_HIP;  // side starts behind the caller's work
+    rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, side);
+    (void)hipEventRecord(ev_diag, side);
+    while (rc == PTA_OK && p.rows > 0) {
+      if (hipStreamWaitEvent(s, ev_diag, 0) != hipSuccess) { rc = PTA_E_HIP; break; }
+      if ((rc = pta_ws_solve_phase(A, lda, strideA, B, algo, p, W, ldw, sW, s)) != PTA_OK) break;
+      const pta_ws_panel q = pta_ws_panel_at(n, NBO, p.pend);
+      const double *Lq = A + (int64_t)q.k0 * lda;                 // rows of panel q, columns to its left
+      rc = pta_dgemm_launch(1, q.nbo, q.nbo, q.k0, -1.0, Lq, lda, 1, Lq, lda, 1.0, A + (int64_t)q.k0 * lda + q.k0, lda, 1, B, strideA, strideA, strideA, algo, s);
+      if (rc != PTA_OK) break;
+      if (hipEventRecord(ev_top, s) != hipSuccess || hipStreamWaitEvent(side, ev_top, 0) != hipSuccess) { rc = PTA_E_HIP; break; }
+      rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, q, W, ldw, sW, side);
+      (void)hipEventRecord(ev_diag, side);
+      if (rc != PTA_OK) break;
+      if (q.rows > 0) {
+        const double *Lr = A + (int64_t)q.pend * lda;             // rows below panel q
+        rc = pta_dgemm_launch(1, q.rows, q.nbo, q.k0, -1.0, Lr, lda, 1, Lq, lda, 1.0, A + (int64_t)q.pend * lda + q.k0, lda, 0, B, strideA, strideA, strideA, algo, s);
+        if (rc != PTA_OK) break;
+      }
+      p = q;
+    }
+    (void)hipStreamWaitEvent(s, ev_diag, 0);  // every exit: the chain's stream never runs ahead of its side stream
+    return rc;
+  }
+  rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, s);
   if (rc != PTA_OK) return rc;
   // block column of panel q (rows from its first column down) -= L[rows, ka:kb] L[panel rows, ka:kb]^T, lower part only
   auto update = [&](const pta_ws_panel &q, int ka, int kb, hipStream_t st) {

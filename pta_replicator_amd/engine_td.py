@@ -197,8 +197,16 @@ class TimeDomainMixin:
             # the panels' diagonal blocks, 10.6 MB per matrix at the default panel width, released right after the factorisation - and
             # the next panel's diagonal phase run ahead on a side stream (PTA_POTRF_DIAG_AHEAD).  68 x 5000^2: 53.2 ms against 56.5 ms
             # without; td_potrf_workspace = False keeps the workspace-free two-chain schedule.
+            # panel order (round 6): "left" (default) = left-looking - a finished panel is not applied to the trailing matrix; each block
+            # column is updated once, right before it is factored, by ONE product over all columns to its left (pta_potrf_batched_ws with
+            # PTA_POTRF_LEFT: 51.2-51.3 ms = 0.70 at 68 x 5000^2 against 52.3-52.6 = 0.69 for "right", the right-looking schedule with the
+            # next panel's diagonal phase run ahead, PTA_POTRF_DIAG_AHEAD; 16 x 10 000^2: 93.0 against 94.1; profiles/r06_potrf_left_looking.txt)
             use_ws = bool(getattr(self, "td_potrf_workspace", True))
-            flags0 = (_lib.POTRF_DIAG_AHEAD if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
+            order = getattr(self, "td_potrf_order", "left")
+            if order not in ("left", "right"):
+                raise ValueError(f"td_potrf_order={order!r}: 'left' or 'right'")
+            ahead = _lib.POTRF_LEFT if (order == "left" and not extra & (_lib.POTRF_DIAG_AHEAD | _lib.POTRF_LEFT)) else _lib.POTRF_DIAG_AHEAD
+            flags0 = (ahead if use_ws else 0) if lookahead else _lib.POTRF_NO_LOOKAHEAD
             flags0 |= extra
             a = 0
             while a < P:

@@ -24,12 +24,17 @@ reps = int(os.environ.get("REPS", "4"))
 def variants(n):
     v = [("right LA c2 (default)", LA), ("right LA c1", LA | _lib.POTRF_CHAINS(1)), ("left c2", L), ("left c1", L | _lib.POTRF_CHAINS(1)),
          ("left c3", L | _lib.POTRF_CHAINS(3)), ("left+split c2", L | S), ("left+split c1", L | S | _lib.POTRF_CHAINS(1)),
-         ("left+split c3", L | S | _lib.POTRF_CHAINS(3))]
+         ("left+split c3", L | S | _lib.POTRF_CHAINS(3)),
+         ("left+diagLA c2", L | LA), ("left+diagLA c1", L | LA | _lib.POTRF_CHAINS(1)), ("left+diagLA c3", L | LA | _lib.POTRF_CHAINS(3)),
+         ("left+diagLA c4", L | LA | _lib.POTRF_CHAINS(4))]
+    if os.environ.get("SHORT"):
+        return v
     for nb in (2, 3, 6, 8):
         if n > nb * 256 * 2:
             v.append((f"left c2 nb{nb * 256}", L | _lib.POTRF_NB(nb)))
             v.append((f"left+split c2 nb{nb * 256}", L | S | _lib.POTRF_NB(nb)))
             v.append((f"right LA c2 nb{nb * 256}", LA | _lib.POTRF_NB(nb)))
+            v.append((f"left+diagLA c2 nb{nb * 256}", L | LA | _lib.POTRF_NB(nb)))
     return v
 
 

@@ -227,7 +227,9 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
                                            (3000, 5, "C4"), (3000, 2, "LA"), (3000, 2, "LAEPI1"), (2500, 2, "NB1LA"), (2501, 3, "NB1C3LA"), (4200, 3, "NB2LA1"), (2500, 2, "D64"), (2501, 2, "NB1D64LA"), (1200, 3, "LA"), (1290, 2, 0),
                                            # left-looking panel order (round 6): pure and with the run-ahead split, 2 .. 11 panels, one / two / three chains, odd order
                                            (3000, 2, "LEFT"), (3000, 2, "LEFTS"), (4200, 3, "LEFTS"), (2500, 2, "NB1LEFT"), (2900, 3, "NB1LEFTSC3"), (2501, 2, "NB1LEFTS"),
-                                           (1200, 3, "LEFTS"), (4300, 1, "NB2LEFTS1")])
+                                           (1200, 3, "LEFTS"), (4300, 1, "NB2LEFTS1"),
+                                           # left-looking with the diagonal phases run ahead on the high-priority side stream (U_top / U_rest)
+                                           (3000, 2, "LEFTLA"), (4200, 3, "LEFTLA"), (2900, 3, "NB1LEFTLAC3"), (2501, 2, "NB1LEFTLA"), (1200, 3, "LEFTLA"), (4300, 1, "NB2LEFTLA1")])
 def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
     over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
@@ -242,7 +244,10 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
           "LEFT": lib.POTRF_LEFT, "LEFTS": lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT, "NB1LEFT": lib.POTRF_NB(1) | lib.POTRF_LEFT,
           "NB1LEFTS": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT,
           "NB1LEFTSC3": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT | lib.POTRF_CHAINS(3),
-          "NB2LEFTS1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT | lib.POTRF_CHAINS(1)}[flags]
+          "NB2LEFTS1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT | lib.POTRF_CHAINS(1),
+          "LEFTLA": lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD, "NB1LEFTLA": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD,
+          "NB1LEFTLAC3": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(3),
+          "NB2LEFTLA1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(1)}[flags]
     rng = np.random.default_rng(n + batch)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
