@@ -356,7 +356,7 @@ typedef struct {
                                  per workgroup), workgroups dealt to the XCDs in contiguous (tile, realisation-group) ranges; 1 = same
                                  kernel in plain linear workgroup order (A/B); 4 / 6 / 8 = all-VALU kernel compiled for that many
                                  waves per SIMD (kept for cross-checks); 100 + k (k <= 64) = the default kernel with k KB of unused
-                                 dynamic LDS per workgroup (occupancy probe, scripts/gpu_synth_occupancy.py) */
+                                 dynamic LDS per workgroup (occupancy probe of round 3: profiles/r03_bench_final.json, DESIGN.md §4.1 "measured and not kept") */
 } pta_engine_plan;
 
 /* coef[(r*P + a)*K + c] = amp[a*K + c] * z(seed, r0+r, (RN,a), c)   (red_noise.py:126-127)   */
@@ -409,14 +409,17 @@ int pta_td_cov_assemble_all(const double *Ft, int64_t ldf, int K, const double *
                             void *stream);
 
 /* The same assembly by the COLUMN-WALKING kernel (ABI 7; 1 <= K <= 64, 64 ldf < 2^29): a wave keeps the phi-scaled operand of 64
- * columns in registers and walks down the rows 16 at a time, every store instruction writes two whole 512-byte row segments; work
- * items = (block, 256-column group, segment of 512 rows), exactly as many as the blocks' orders need - a ragged array launches no
- * empty workgroups.  pta_td_cov_walk_items writes item0[b] = first item of block b (b <= n_blocks: item0[n_blocks] = the total,
+ * columns in registers and walks down the rows 16 at a time; a store instruction writes four rows x 256 bytes (whole cache lines: a
+ * lane's accumulators hold two neighbouring columns, 16 bytes per lane); work items = (block, 256-column group, segment of 512 rows),
+ * exactly as many as the blocks' orders need - a ragged array launches no empty workgroups.
+ * PRECONDITION (as for pta_td_plan): blk_pos[b] and blk_ld[b] must be EVEN - the 16-byte stores assume it; the entry point checks the
+ * alignment of Cbase only (the arrays live on the device), engine_td builds both even (orders padded to even, pitches to 16).  pta_td_cov_walk_items writes item0[b] = first item of block b (b <= n_blocks: item0[n_blocks] = the total,
  * also returned; -1 on a bad argument) from the HOST copy of the orders; the caller keeps a device copy of item0 for the launch.
  * Every k index is clamped to K - 1 before it forms an address: nothing behind the [K, ldf] design matrix is ever read.
  * epoch_first (optional, device, indexed like epoch_of): the smallest TOA index INSIDE ITS BLOCK that shares the TOA's epoch - lets a step
  * whose rows have no epoch partner among the wave's columns skip the ECORR arithmetic (every step off the diagonal for time-ordered
- * TOAs); NULL keeps it everywhere.  variant (the SAME K and variant for both calls): 0 / 1 (reserved for further work-item geometries). */
+ * TOAs); NULL keeps it everywhere.  variant (the SAME K and variant for both calls): 0 or 1 are accepted and select the SAME kernel
+ * (reserved for further work-item geometries). */
 int64_t pta_td_cov_walk_items(const int32_t *blk_n_host, int n_blocks, int K, int variant, int32_t *item0_host);
 int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double *phi, const double *sigma2,
                              const int32_t *epoch_of, const double *ecorr2, double *Cbase, const int64_t *blk_pos,
@@ -437,8 +440,8 @@ int pta_td_trmm(const double *L, int64_t ldl, int N, const double *z, int64_t ld
  *                        (stream_kind, m % P)   (the npts x npts factor of the GWB grid covariance)
  * Factor b is row-major at Lbase + blk_pos[b] with leading dimension blk_ld[b]; blk_pos and blk_ld must be EVEN (16-byte
  * double2 loads) and only elements on or below the diagonal are read (pta_potrf_batched_ex may leave the upper triangle
- * unzeroed).  Work items = strips of PTA_TD_STRIP consecutive rows of one factor, sorted by the caller by decreasing
- * min(n, n0 + PTA_TD_STRIP) (their K extent) so that the long strips start first.
+ * unzeroed).  Work items = strips of up to PTA_TD_STRIP consecutive rows of one factor (item_n0, item_rows), sorted by the caller by
+ * decreasing min(n, n0 + rows) (their K extent) so that the long strips start first.
  * Optional epilogue (rows_per_real == 1 only): gw_G[(m * n_blocks + b) * gw_npts + j] is the mixed GWB grid series of
  * (realisation m, pulsar b), interpolated with gw_jlo / gw_w exactly as pta_engine_synth does (red_noise.py:286-287);
  * det is added to every row.  All three are indexed by OUTPUT column.                                              */
@@ -450,7 +453,7 @@ typedef struct {
   const int32_t *blk_n;       /* [n_blocks] order of factor b */
   const int32_t *blk_off;     /* [n_blocks] first output column of block b */
   const int32_t *item_blk;    /* [n_items] factor block of the strip */
-  const int32_t *item_n0;     /* [n_items] first row of the strip (multiple of PTA_TD_STRIP) */
+  const int32_t *item_n0;     /* [n_items] first row of the strip (a multiple of 16; of PTA_TD_STRIP when item_rows is NULL) */
   int32_t n_blocks;
   int32_t n_items;
   int32_t rows_per_real;
@@ -469,6 +472,12 @@ typedef struct {
                                  behind the last block" of ABI 5 is gone - the kernel clamps whole groups and zeroes k >= blk_n[b]) */
   int64_t ld_z;
   const int32_t *blk_zoff;    /* [n_blocks] first column of block b's deviates inside a row of z (even: pta_rng_fill_normal writes pairs) */
+  const int32_t *item_rows;   /* ABI 8: [n_items] rows of the strip (1 .. PTA_TD_STRIP), or NULL = PTA_TD_STRIP for every strip (cut at the factor's
+                                 last row).  Lets the caller put a factor's PARTIAL strip FIRST (rows [0, f), K extent f <= 256) instead of last
+                                 (K extent = the factor's order): a strip always costs 16 column tiles per K slab, so the dead tiles of a
+                                 partial strip are multiplied by its K - 7 of 16 tiles x K = 5000 per 5000-TOA pulsar = 3.9 % of the launch
+                                 when the partial strip is the last one, nothing to speak of when it is the first (round 6).  Strips of one
+                                 factor must tile its rows without overlap. */
 } pta_td_plan;
 
 int pta_td_trmm_rng(const pta_td_plan *plan_host, uint64_t seed, uint64_t r0, int M, double *out, int64_t ld_out, void *stream);

@@ -57,7 +57,7 @@ class TdPlan(ctypes.Structure):
         ("Lbase", _P), ("blk_pos", _P), ("blk_ld", _P), ("blk_n", _P), ("blk_off", _P), ("item_blk", _P), ("item_n0", _P),
         ("n_blocks", c_int32), ("n_items", c_int32), ("rows_per_real", c_int32), ("stream_kind", c_uint32),
         ("rng_fast", c_int32), ("gw_npts", c_int32),
-        ("gw_G", _P), ("gw_jlo", _P), ("gw_w", _P), ("det", _P), ("z", _P), ("ld_z", c_int64), ("blk_zoff", _P),
+        ("gw_G", _P), ("gw_jlo", _P), ("gw_w", _P), ("det", _P), ("z", _P), ("ld_z", c_int64), ("blk_zoff", _P), ("item_rows", _P),
     ]
 
 

@@ -108,7 +108,10 @@ def ra_dec(psr, default=None):
     on that path request with default=(0.0, 0.0); add_cgw fails on it (deterministic.py:76-91), as this does without a default."""
     loc = psr.loc
     if "DEC_RAD" in loc and "RA_RAD" in loc:   # simulate.from_enterprise: the radians an enterprise-style pulsar carried, unrounded
-        return float(loc["RA_RAD"]), float(loc["DEC_RAD"])
+        # ... as long as they still describe the position RAJ / DECJ give: a caller who edits RAJ / DECJ afterwards means those (ADVICE r5)
+        if "DECJ" not in loc or (abs(float(loc["RAJ"]) * np.pi / 12.0 - float(loc["RA_RAD"])) < 1e-12
+                                 and abs(float(loc["DECJ"]) * np.pi / 180.0 - float(loc["DEC_RAD"])) < 1e-12):
+            return float(loc["RA_RAD"]), float(loc["DEC_RAD"])
     if "DECJ" in loc:
         return float(loc["RAJ"] * np.pi / 12.0), float(loc["DECJ"] * np.pi / 180.0)
     if "ELAT" in loc:

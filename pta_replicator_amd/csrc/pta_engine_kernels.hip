@@ -351,13 +351,13 @@ extern "C" int pta_engine_synth(const pta_engine_plan *plan_host, uint64_t seed,
   PTA_REQUIRE(!p.wn_c || !p.wn_a, PTA_E_ARG, "pta_engine_synth: wn_c (single-deviate white noise) replaces wn_a / wn_b - pass one or the other");
   PTA_REQUIRE(!p.ecorr_toa || p.epoch_of, PTA_E_ARG, "pta_engine_synth: epoch_of missing");
   // 0 = MFMA kernel (default); 1 = same, linear workgroup order; 4 / 6 / 8 = all-VALU kernel; 100 + k = MFMA kernel with k KB of
-  // unused dynamic LDS per workgroup - the occupancy probe of scripts/gpu_synth_occupancy.py: the 34 KB ECORR staging buffer allows 4
+  // unused dynamic LDS per workgroup - the occupancy probe of round 3 (script since removed; result in DESIGN.md §4.1): the 34 KB ECORR staging buffer allows 4
   // workgroups per CU (+12 KB: 3, +20 KB: 2).  Measured step time 10.3 / 7.2 / 5.9 / 5.5 ms at 1 / 2 / 3 / 4 workgroups; a two-pass
   // staging variant (17 KB, 6 per CU, 3 barriers) measured 6.0 ms at 6 AND when padded back to 4: occupancy is saturated at 4.
   const int variant = p.synth_variant;
   const int rng_fast = p.rng_fast ? 1 : 0;
   // 0 = MFMA kernel (default); 1 = same, linear workgroup order (A/B of the XCD mapping); 4 / 6 / 8 = all-VALU kernel; 100 + k = MFMA
-  // kernel with k KB of unused dynamic LDS per workgroup - the occupancy probe of scripts/gpu_synth_occupancy.py: the 34 KB ECORR
+  // kernel with k KB of unused dynamic LDS per workgroup - the occupancy probe of round 3 (script since removed; result in DESIGN.md §4.1): the 34 KB ECORR
   // staging buffer allows 4 workgroups per CU (+12 KB: 3, +20 KB: 2)
   if (variant == 0 || variant == 1 || (variant >= 100 && variant <= 164)) {
     const int xcd = variant == 1 ? 0 : 1;

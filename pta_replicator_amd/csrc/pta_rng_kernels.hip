@@ -55,18 +55,28 @@ extern "C" int pta_rng_fill_normal(uint64_t seed, uint64_t r0, int R, uint32_t s
 
 // The same fill for ALL blocks of a TD plan in one launch: block b's deviates (stream (stream_kind, b), n = blk_n[b], pairs written
 // whole) go to z[r * ld + blk_zoff[b] ..] - what k_td_trmm_rng / k_td_trmm_z128 read through pta_td_plan.z.  68 launches of the
-// per-block form cost 1.1 ms per 1024 realisations of the 68 x 5000 array, this one 0.6.
+// per-block form cost 1.1 ms per 1024 realisations of the 68 x 5000 array, this one 0.6 alone (1.6 beside the GWB grid stage; see FILL_ROWS).
+// A workgroup draws the same 256 pairs of FILL_ROWS consecutive rows: the 2.5 KB table staging (a global read + a barrier) and the
+// block's layout loads are paid once per 2048 pairs instead of once per 256 - with one row per workgroup the launch was 696 k workgroups
+// of ~0.4 us of arithmetic behind ~1.5 us of load latency each: 1.59 ms per 1024 realisations of the 68 x 5000 array = 0.22 T normals/s
+// against the 0.59 T/s of the in-library RNG microbenchmark, and it sits in front of every L.z product (round 6).
+#define FILL_ROWS 8
 __global__ void k_fill_normal_blocks(uint64_t seed, uint64_t r0, uint32_t stream_kind, const int32_t *__restrict__ blk_n,
-                                     const int32_t *__restrict__ blk_zoff, double *__restrict__ z, int64_t ld, int fast) {
+                                     const int32_t *__restrict__ blk_zoff, double *__restrict__ z, int64_t ld, int fast, int R) {
   pta_rng_stage_tables();
   __syncthreads();
   const int b = blockIdx.z;
   const int npairs = (blk_n[b] + 1) >> 1;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npairs) return;
-  double a, c;
-  pta_normal_pair(seed, r0 + (uint64_t)blockIdx.y, pta_stream_id(stream_kind, (uint32_t)b), (uint32_t)p, a, c, fast);
-  *reinterpret_cast<double2 *>(z + (int64_t)blockIdx.y * ld + blk_zoff[b] + 2 * (int64_t)p) = make_double2(a, c);
+  const uint32_t sid = pta_stream_id(stream_kind, (uint32_t)b);
+  double *__restrict__ zp = z + blk_zoff[b] + 2 * (int64_t)p;
+  const int rbeg = blockIdx.y * FILL_ROWS, rend = min(R, rbeg + FILL_ROWS);
+  for (int r = rbeg; r < rend; ++r) {
+    double a, c;
+    pta_normal_pair(seed, r0 + (uint64_t)r, sid, (uint32_t)p, a, c, fast);
+    *reinterpret_cast<double2 *>(zp + (int64_t)r * ld) = make_double2(a, c);
+  }
 }
 
 extern "C" int pta_rng_fill_normal_blocks(uint64_t seed, uint64_t r0, int R, uint32_t stream_kind, int n_blocks, const int32_t *blk_n,
@@ -75,8 +85,8 @@ extern "C" int pta_rng_fill_normal_blocks(uint64_t seed, uint64_t r0, int R, uin
   PTA_REQUIRE(R > 0 && R <= 65535 && n_blocks > 0 && n_blocks <= 65535 && max_n > 0, PTA_E_ARG,
               "pta_rng_fill_normal_blocks: R=%d n_blocks=%d max_n=%d", R, n_blocks, max_n);
   PTA_REQUIRE(ld % 2 == 0 && ((uintptr_t)z % 16) == 0, PTA_E_ARG, "pta_rng_fill_normal_blocks: even ld and a 16-byte aligned z needed");
-  hipLaunchKernelGGL(k_fill_normal_blocks, dim3(pta_cdiv((max_n + 1) / 2, 256), R, n_blocks), dim3(256), 0, pta_stream(stream), seed, r0,
-                     stream_kind, blk_n, blk_zoff, z, ld, rng_fast ? 1 : 0);
+  hipLaunchKernelGGL(k_fill_normal_blocks, dim3(pta_cdiv((max_n + 1) / 2, 256), pta_cdiv(R, FILL_ROWS), n_blocks), dim3(256), 0, pta_stream(stream),
+                     seed, r0, stream_kind, blk_n, blk_zoff, z, ld, rng_fast ? 1 : 0, R);
   PTA_LAUNCH_CHECK();
   return PTA_OK;
 }

@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
   const double *__restrict__ L = pl.Lbase + pl.blk_pos[blk];
   const int t = threadIdx.x, l = t & 63, wv = t >> 6;
   const int c = l & 15, q = l >> 4;
-  const int kend = min(n, n0 + TDS_N);  // L[i, j] = 0 for j > i: columns beyond the strip's last row contribute nothing
+  const int srows = pl.item_rows ? pl.item_rows[item] : TDS_N;  // rows of this strip (a factor's partial strip may be its FIRST: pta_td_plan.item_rows)
+  const int kend = min(n, n0 + srows);  // L[i, j] = 0 for j > i: columns beyond the strip's last row contribute nothing
   const int nslab = (kend + TDS_K - 1) / TDS_K;
   typedef double pta_f64x2 __attribute__((ext_vector_type(2)));
 
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
     zrow = pl.z + (int64_t)min(m_a, M - 1) * pl.ld_z + pl.blk_zoff[blk];
     zfetch(0);
   }
-  const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 256)
+  const int sdiag = n0 / TDS_K;  // first slab that holds an element above the diagonal (n0 is a multiple of 16)
   auto slab = [&](int s, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
     const int cur = s & 1, k0 = s * TDS_K;
@@ -802,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void k_td_trmm_rng(pta_td_plan pl, uint64_t
 #pragma unroll
   for (int j = 0; j < TDS_NT; ++j) {
     const int i = n0 + 16 * j + c;
-    if (i >= n) continue;
+    if (i >= n || 16 * j + c >= srows) continue;  // past the factor, or a row of the NEXT strip (computed on a cut K range: not this strip's to store)
     const int64_t oc = (int64_t)ocol0 + i;
     double add = 0.0, wgt = 0.0;
     int jl = 0;

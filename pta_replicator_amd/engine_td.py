@@ -36,10 +36,23 @@ STREAM_TD, STREAM_TDGW = 5, 6
 
 
 def _strips(counts, strip=_lib.TD_STRIP):
-    """work items (block, first row) of the triangular product, longest K extent first."""
-    items = [(min(int(n), n0 + strip), b, n0) for b, n in enumerate(counts) for n0 in range(0, int(n), strip)]
+    """work items (block, first row, rows) of the triangular product, longest K extent first.  A factor whose order is not a multiple of
+    the strip height gets its PARTIAL strip first - rows [0, f), f = (n mod strip) rounded up to 16 - and whole strips behind it: a strip
+    costs 16 column tiles per K slab whatever its height, so a partial strip should be the one with the SHORTEST K extent (f columns),
+    not the longest (n columns: 7 of 16 tiles x K = 5000 of a 5000-TOA pulsar, 3.9 % of the launch's matrix-pipe work)."""
+    items = []
+    for b, n in enumerate(counts):
+        n = int(n)
+        f = n % strip
+        first = strip if f == 0 else min(strip, (f + 15) // 16 * 16)
+        n0 = 0
+        while n0 < n:
+            rows = min(first if n0 == 0 else strip, n - n0)
+            items.append((min(n, n0 + rows), b, n0, rows))
+            n0 += rows
     items.sort(key=lambda x: -x[0])
-    return np.array([x[1] for x in items], dtype=np.int32), np.array([x[2] for x in items], dtype=np.int32)
+    return (np.array([x[1] for x in items], dtype=np.int32), np.array([x[2] for x in items], dtype=np.int32),
+            np.array([x[3] for x in items], dtype=np.int32))
 
 
 class TimeDomainMixin:
@@ -75,11 +88,11 @@ class TimeDomainMixin:
         # asynchronous sequence bit-equal to a fully serialised one.
         self.td_assemble()
         self.td_factorise(lookahead=lookahead)
-        blk, n0 = _strips(counts)
-        self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0)]
+        blk, n0, rows = _strips(counts)
+        self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0), dv.i32(rows)]
         tp = _lib.TdPlan()
         tp.Lbase = self.d_Ltd.data_ptr()
-        tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in self._td_keep]
+        tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0, tp.item_rows = [x.data_ptr() for x in self._td_keep]
         tp.n_blocks, tp.n_items, tp.rows_per_real, tp.stream_kind, tp.rng_fast = P, len(blk), 1, STREAM_TD, 0
         tp.det = pl.det
         self.td_plan = tp
@@ -112,7 +125,7 @@ class TimeDomainMixin:
         if kernel == "walk":
             if not walk_ok:
                 raise ValueError(f"td_cov_kernel='walk' needs 1 <= K <= 64 red-noise columns and 64 n_toa < 2^29 (K={K}, n_toa={N})")
-            variant = int(getattr(self, "td_cov_walk_variant", 0))     # pta_td_cov_assemble_walk: 0 = default, 1 / 2 = its two forms
+            variant = int(getattr(self, "td_cov_walk_variant", 0))     # pta_td_cov_assemble_walk: 0 (default) or 1, one kernel either way (reserved)
             items = getattr(self, "_td_walk_items", None)
             if items is None or items[0] != (tuple(counts), K, variant):
                 h_n = np.ascontiguousarray(counts, dtype=np.int32)
@@ -258,15 +271,15 @@ class TimeDomainMixin:
                 raise np.linalg.LinAlgError("GWB grid covariance is not positive definite even with 1e-8 relative jitter")
         self.gw_td_jitter = eps
         self.d_Lg, self.td_ldg = Lg, ldg
-        gblk, gn0 = _strips([npts])
-        self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0)]
+        gblk, gn0, grows = _strips([npts])
+        self._tdgw_keep = [dv.i64([0]), dv.i32([ldg]), dv.i32([npts]), dv.i32([0]), dv.i32(gblk), dv.i32(gn0), dv.i32(grows)]
         # "memory" draws of the grid stage: one row of npts (rounded up to even) deviates per (realisation, pulsar), written by
         # pta_rng_fill_normal_blocks as P blocks of a realisation's row - stream (TDGW, pulsar), the numbers the register form draws
         self._tdgw_zld = (npts + 1) // 2 * 2
         self._tdgw_fill = [dv.i32([npts] * P), dv.i32(np.arange(P) * self._tdgw_zld), dv.i32([0])]
         gp = _lib.TdPlan()
         gp.Lbase = Lg.data_ptr()
-        gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0 = [x.data_ptr() for x in self._tdgw_keep]
+        gp.blk_pos, gp.blk_ld, gp.blk_n, gp.blk_off, gp.item_blk, gp.item_n0, gp.item_rows = [x.data_ptr() for x in self._tdgw_keep]
         gp.n_blocks, gp.n_items, gp.rows_per_real, gp.stream_kind, gp.rng_fast = 1, len(gblk), P, STREAM_TDGW, 0
         self.tdgw_plan = gp
         self._gw_grid_ready = True

@@ -140,7 +140,17 @@ class EnterpriseTOAs(ArrayTOAs):
     def __init__(self, toas_s, toaerrs_s, flags=None, freqs_mhz=1440.0):
         toas_s = np.asarray(toas_s, dtype=np.float64)
         super().__init__(toas_s.astype(np.longdouble) / np.longdouble(86400.0), np.asarray(toaerrs_s, dtype=np.float64) * 1e6, flags, freqs_mhz)
-        self.errors_s = np.array(toaerrs_s, dtype=np.float64) * np.ones(len(toas_s))
+        self.errors_s = np.array(toaerrs_s, dtype=np.float64) * np.ones(len(toas_s))   # the caller's numbers, bit for bit
+
+    # ONE error column: the seconds the caller handed over.  ``errors_us`` - what ArrayTOAs' own code (the errors_seconds()
+    # cache check, write_tim, to_enterprise) reads and what a caller may rescale - is a VIEW of it: assigning errors_us updates the seconds.
+    @property
+    def errors_us(self):
+        return self.errors_s * 1e6
+
+    @errors_us.setter
+    def errors_us(self, value):
+        self.errors_s = np.asarray(value, dtype=np.float64) * 1e-6
 
     def get_errors(self):
         return self.errors_s.copy() * u.s

@@ -27,7 +27,7 @@ def gpu():
     return {"torch": torch, "lib": _lib, "dv": dv, "s": dv.stream_ptr()}
 
 
-def _plan(gpu, Ls, lds, rows_per_real, kind, keep):
+def _plan(gpu, Ls, lds, rows_per_real, kind, keep, old_strips=False):
     """pta_td_plan over a list of host factors (row-major, leading dimension lds[b]); the upper triangles hold NaN."""
     lib, dv = gpu["lib"], gpu["dv"]
     from pta_replicator_amd.engine_td import _strips
@@ -39,12 +39,18 @@ def _plan(gpu, Ls, lds, rows_per_real, kind, keep):
         il = np.tril_indices(ns[b])
         v[il] = L[il]
     off = np.concatenate([[0], np.cumsum(ns)]).astype(np.int32)
-    blk, n0 = _strips(ns)
+    blk, n0, rows = _strips(ns)
+    if old_strips:   # the layout of rounds 2-5: strips at multiples of PTA_TD_STRIP, item_rows = NULL (the partial strip last)
+        items = sorted([(min(int(n), k + 256), b, k) for b, n in enumerate(ns) for k in range(0, int(n), 256)], key=lambda x: -x[0])
+        blk, n0, rows = np.array([x[1] for x in items], dtype=np.int32), np.array([x[2] for x in items], dtype=np.int32), None
     dev = [dv.f64(buf), dv.i64(pos[:-1]), dv.i32(lds), dv.i32(ns), dv.i32(off[:-1] if rows_per_real == 1 else [0]), dv.i32(blk), dv.i32(n0)]
+    if rows is not None:
+        dev.append(dv.i32(rows))
     keep.extend(dev)
     tp = lib.TdPlan()
     tp.Lbase = dev[0].data_ptr()
-    tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in dev[1:]]
+    tp.blk_pos, tp.blk_ld, tp.blk_n, tp.blk_off, tp.item_blk, tp.item_n0 = [x.data_ptr() for x in dev[1:7]]
+    tp.item_rows = dev[7].data_ptr() if rows is not None else None
     tp.n_blocks, tp.n_items, tp.rows_per_real, tp.stream_kind, tp.rng_fast = len(Ls), len(blk), rows_per_real, kind, 0
     return tp, off
 
@@ -81,6 +87,39 @@ def test_td_trmm_rng_per_pulsar_blocks(gpu, sizes, R):
             z = _normals(gpu, seed, r0 + m, 5, b, n)
             ref = L @ z
             assert np.max(np.abs(got[m, off[b]:off[b] + n] - ref)) < 1e-12 * max(1.0, np.max(np.abs(ref))), (b, m)
+
+
+@pytest.mark.parametrize("zmem", [False, True])
+def test_td_trmm_partial_strip_first_is_bit_identical_to_partial_strip_last(gpu, zmem):
+    """round 6: pta_td_plan.item_rows lets a factor's partial strip come FIRST (rows [0, f), K extent f) instead of last (K extent = the
+    factor's order: 7 of 16 column tiles of every slab dead at 5000 TOAs).  Same accumulators, same K order per output element: the
+    output must be BIT-identical to the rounds 2-5 layout (strips at multiples of 256, item_rows = NULL) - orders on both sides of every
+    boundary (f = 16 k, 16 k + 1, 255, 256, 257, below one strip, 5000 and 600 themselves), register and memory deviates."""
+    lib, dv, torch = gpu["lib"], gpu["dv"], gpu["torch"]
+    sizes, R = (5000, 600, 257, 255, 256, 272, 273, 17, 1, 513, 1000), 70
+    rng = np.random.default_rng(77)
+    Ls = [np.tril(rng.standard_normal((n, n))) / np.sqrt(n) + 3 * np.eye(n) for n in sizes]
+    lds = [(n + 1) // 2 * 2 + (2 if b % 2 else 0) for b, n in enumerate(sizes)]
+    outs = []
+    for old in (True, False):
+        keep = []
+        tp, off = _plan(gpu, Ls, lds, 1, 5, keep, old_strips=old)
+        ntot = int(off[-1])
+        seed, r0 = 99, 1234567890123
+        if zmem:
+            zoff = np.concatenate([[0], np.cumsum((np.array(sizes) + 1) // 2 * 2)]).astype(np.int32)
+            z = dv.zeros((R, int(zoff[-1]) + 16))
+            keep += [dv.i32(list(sizes)), dv.i32(zoff[:-1])]
+            lib.call("pta_rng_fill_normal_blocks", seed, r0, R, 5, len(sizes), dv.ptr(keep[-2]), dv.ptr(keep[-1]), int(max(sizes)), dv.ptr(z), z.stride(0), 0, gpu["s"])
+            tp.z, tp.ld_z, tp.blk_zoff = z.data_ptr(), z.stride(0), keep[-1].data_ptr()
+        out = dv.f64(np.full((R, ntot + 3), 7.0))
+        lib.call("pta_td_trmm_rng", ctypes.byref(tp), seed, r0, R, dv.ptr(out), ntot + 3, gpu["s"])
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.all(outs[1][:, -3:] == 7.0) and np.all(np.isfinite(outs[1]))
+    z0 = _normals(gpu, 99, 1234567890123, 5, 0, 5000)
+    ref = Ls[0] @ z0
+    assert np.max(np.abs(outs[1][0, :5000] - ref)) < 1e-12 * np.max(np.abs(ref))
 
 
 def test_td_trmm_rng_shared_grid_factor(gpu):
