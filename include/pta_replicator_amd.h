@@ -426,6 +426,22 @@ int pta_td_cov_assemble_walk(const double *Ft, int64_t ldf, int K, const double 
                              const int32_t *blk_ld, const int32_t *blk_n, const int32_t *blk_off, int n_blocks,
                              const int32_t *item0, int64_t n_items, const int32_t *epoch_first, int variant, void *stream);
 
+/* ASSEMBLY + FACTORISATION of a uniform batch in one call (ABI 8; csrc/pta_td_fused.hip): the covariances are never written.  In the
+ * left-looking panel order a tile of the lower triangle is touched once before its panel is factored - by its block column's update
+ * C - L[:, <k0] L[:, <k0]^T - so that update COMPUTES C = F diag(phi) F^T + diag(sigma2) + ECORR (red_noise.py:98-101,126-128,
+ * white_noise.py:105-109,182) in front of the factor product (four more K slabs of the same MFMA stream) and stores without reading:
+ * no assembly launch, no 2 x 8 bytes per element of round trip (6.8 GB written + read at 68 x 5000^2).
+ *   Fr [B n, 64]  row-major rows of the design matrix over the batch's concatenated TOAs (matrix b's rows = [b n, (b + 1) n)), columns
+ *                 >= kf ZERO;   Gr [B n, 64] = -phi_k Fr[i, k];   kf = red-noise columns in use (0 .. 64; 0 skips the phase)
+ *   sigma2 [B n], epoch_of [B n] / ecorr2 [B n] (both or neither NULL): as pta_td_cov_assemble_all
+ *   A, n, lda, strideA, B, info, flags, work, work_doubles: as pta_potrf_batched_ws (A's contents are ignored; PTA_POTRF_LEFT is implied;
+ *   the workspace scheme must apply: n > panel width and a workspace of pta_potrf_workspace_doubles(n, B, flags) doubles; n, lda, strideA
+ *   even).  The factors equal pta_td_cov_assemble_walk + pta_potrf_batched_ws(PTA_POTRF_LEFT) to rounding (the K = 60 product is summed
+ *   in another order), not bit for bit. */
+int pta_td_assemble_potrf(const double *Fr, const double *Gr, int kf, const double *sigma2, const int32_t *epoch_of, const double *ecorr2,
+                          double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
+                          int64_t work_doubles, void *stream);
+
 /* out[r*ld_out + i] (+)= sum_{j<=i} L[i*ldl + j] z[r*ld_z + j]   (L z, the draw of the dense path;
  * Z . L^T on the fp64 MFMA GEMM).  z holds N(0,1) deviates: NumPy's in replay mode, or
  * pta_rng_fill_normal(stream (TD, pulsar)) in throughput mode.                              */

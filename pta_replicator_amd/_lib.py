@@ -85,6 +85,7 @@ _SIGNATURES = {
     "pta_potrf_workspace_doubles": (c_int64, [c_int, c_int, c_int]),
     "pta_potrf_batched_ws": (c_int, [_P, c_int, c_int64, c_int64, c_int, _P, c_int, _P, c_int64, _P]),
     "pta_potrf_warmup": (c_int, [c_int]),
+    "pta_td_assemble_potrf": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int64, c_int, _P, c_int, _P, c_int64, _P]),
     "pta_potrf_ragged_plan_words": (c_int64, [c_int]),
     "pta_potrf_ragged_plan": (c_int, [_P, _P, _P, c_int, c_int, _P, POINTER(c_int64)]),
     "pta_potrf_ragged": (c_int, [_P, _P, _P, _P, _P, c_int64, _P]),

@@ -62,3 +62,16 @@ struct pta_rag {
 // lower_only: only c0 + n <= r0 + m (the caller passes r0 == c0 for square updates).  Needs algo >= 1 kernels; all origins even.
 int pta_dgemm_launch_rag(int M, int N, int K, double alpha, double *Abase, int r0, int c0, int k0, const double *Bws, int64_t ldb, int64_t sB,
                          double beta, int lower_only, int batch, pta_rag rg, hipStream_t stream);
+
+// ---- assembly operands of the fused left-looking factorisation (pta_td_assemble_potrf; csrc/pta_td_fused.hip) ---------------------------
+// Device pointers over the concatenated TOAs of a UNIFORM batch (matrix z's TOAs are [z toa_stride, (z + 1) toa_stride)):
+struct pta_fuse {
+  const double *Fr;       // [sum N, 64] row-major rows of the Fourier design matrix (red_noise.py:98-101), columns >= kf zero
+  const double *Gr;       // [sum N, 64] = -phi_k Fr[i, k] (phi = the prior variances, red_noise.py:126)
+  const double *sigma2;   // [sum N] white-noise variances (white_noise.py:105-109)
+  const int32_t *epoch;   // [sum N] ECORR epoch of every TOA (white_noise.py:7-44), or NULL
+  const double *ecorr2;   // [sum N] ecorr^2 of the TOA's epoch (white_noise.py:182), or NULL
+  int64_t toa_stride;     // TOAs per matrix
+  int32_t kf;             // red-noise columns in use (0 = none: the design-matrix phase is skipped)
+};
+int pta_td_fused_launch(int M, int N, int K, double *L, int64_t ld, int64_t sL, int r0, int batch, const pta_fuse &fz, hipStream_t stream);

@@ -963,7 +963,24 @@ static int pta_potrf_chain_ws_lookahead(double *A, int n, int64_t lda, int64_t s
 // substitution (the left-looking counterpart of PTA_POTRF_DIAG_AHEAD); U_b(q), K = [k0_{q-1}, k0_q), follows solve(q - 1) on the chain's
 // stream.  Same kernels, same workspace, same diagonal / substitution phases as the right-looking chains above.
 static int pta_potrf_chain_ws_left(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, int algo, int NBO, double *W,
-                                   int64_t sW, hipStream_t s, hipStream_t side, hipEvent_t ev_solved, hipEvent_t ev_ua) {
+                                   int64_t sW, hipStream_t s, hipStream_t side, hipEvent_t ev_solved, hipEvent_t ev_ua, const pta_fuse *fz = nullptr) {
+  if (fz) {
+    // FUSED ASSEMBLY (pta_td_assemble_potrf; csrc/pta_td_fused.hip): nothing has been written to A - every block column is COMPUTED by its
+    // one update, F phi F^T + diag + ECORR - L[:, <k0] L[:, <k0]^T, block column 0 (nothing to its left) first.  Plain left-looking order.
+    const int64_t ldw = pta_potrf_ws_ld(NBO);
+    pta_ws_panel p = pta_ws_panel_at(n, NBO, 0);
+    int rc = pta_td_fused_launch(n, p.nbo, 0, A, lda, strideA, 0, B, *fz, s);
+    if (rc != PTA_OK) return rc;
+    if ((rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, p, W, ldw, sW, s)) != PTA_OK) return rc;
+    while (p.rows > 0) {
+      if ((rc = pta_ws_solve_phase(A, lda, strideA, B, algo, p, W, ldw, sW, s)) != PTA_OK) return rc;
+      const pta_ws_panel q = pta_ws_panel_at(n, NBO, p.pend);
+      if ((rc = pta_td_fused_launch(n - q.k0, q.nbo, q.k0, A, lda, strideA, q.k0, B, *fz, s)) != PTA_OK) return rc;
+      if ((rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, q, W, ldw, sW, s)) != PTA_OK) return rc;
+      p = q;
+    }
+    return PTA_OK;
+  }
   const bool split = (flags & PTA_POTRF_LEFT_SPLIT) != 0 && side != nullptr;
   const int64_t ldw = pta_potrf_ws_ld(NBO);
   pta_ws_panel p = pta_ws_panel_at(n, NBO, 0);
@@ -1048,7 +1065,7 @@ static int pta_potrf_chain_ws_left(double *A, int n, int64_t lda, int64_t stride
 // instead of inside one matrix (an in-matrix look-ahead, next panel on a high-priority stream beside the bulk update, measured
 // slower: it splits every trailing update in two and the concurrent halves slow each other down).
 static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
-                          int64_t work_doubles, void *stream) {
+                          int64_t work_doubles, void *stream, const pta_fuse *fz = nullptr) {
   PTA_REQUIRE(A && info, PTA_E_ARG, "pta_potrf_batched: NULL argument");
   PTA_REQUIRE(n > 0 && n <= 65535 && B > 0 && B <= 65535, PTA_E_ARG, "pta_potrf_batched: n=%d B=%d", n, B);
   PTA_REQUIRE(lda >= n && (B == 1 || strideA >= (int64_t)(n - 1) * lda + n), PTA_E_ARG, "pta_potrf_batched: lda=%lld strideA=%lld too small",
@@ -1074,6 +1091,8 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
     return use_ws ? pta_potrf_step_ws(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, Wb, sWm, st, ev)
                   : pta_potrf_step(Ab, n, lda, strideA, Bc, infob, flags, algo, NBO, k0p, st);
   };
+  PTA_REQUIRE(!fz || (use_ws && (flags & PTA_POTRF_LEFT) && !(flags & (PTA_POTRF_NO_LOOKAHEAD | PTA_POTRF_LEFT_SPLIT | PTA_POTRF_DIAG_AHEAD)) && algo >= 2),
+              PTA_E_ARG, "pta_td_assemble_potrf: needs the workspace scheme (n > panel width, workspace of pta_potrf_workspace_doubles) in plain left-looking order");
   PTA_HIP(hipMemsetAsync(info, 0, sizeof(int32_t) * B, s));
   if (use_ws && (flags & (PTA_POTRF_DIAG_AHEAD | PTA_POTRF_LEFT)) && !(flags & PTA_POTRF_NO_LOOKAHEAD)) {
     pta_potrf_ctx *cx = nullptr;
@@ -1085,9 +1104,16 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
       const int b0 = (int)((int64_t)B * c / nchain), b1 = (int)((int64_t)B * (c + 1) / nchain);
       hipStream_t sc = nchain == 1 ? s : cx->chain[c];
       if (nchain > 1) PTA_HIP(hipStreamWaitEvent(sc, cx->ev_in, 0));
+      pta_fuse fc;
+      if (fz) {  // this chain's matrices: the assembly operands start b0 matrices further on
+        fc = *fz;
+        const int64_t o = (int64_t)b0 * fz->toa_stride;
+        fc.Fr += o * 64, fc.Gr += o * 64, fc.sigma2 += o;
+        if (fc.epoch) fc.epoch += o, fc.ecorr2 += o;
+      }
       rc_chain = (flags & PTA_POTRF_LEFT)
                      ? pta_potrf_chain_ws_left(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO, work + (int64_t)b0 * sWm, sWm,
-                                               sc, cx->side[c], cx->ev_u1[c], cx->ev_la[c])
+                                               sc, cx->side[c], cx->ev_u1[c], cx->ev_la[c], fz ? &fc : nullptr)
                      : pta_potrf_chain_ws_lookahead(A + (int64_t)b0 * strideA, n, lda, strideA, b1 - b0, info + b0, flags, algo, NBO,
                                                     work + (int64_t)b0 * sWm, sWm, sc, cx->side[c], cx->ev_u1[c], cx->ev_la[c]);
     }
@@ -1405,6 +1431,18 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
 extern "C" int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags,
                                     void *stream) {
   return pta_potrf_impl(A, n, lda, strideA, B, info, flags, nullptr, 0, stream);
+}
+
+// Assembly + factorisation of a uniform batch of TD covariances in one call: the matrices are never written as covariances - every block
+// column is computed by its left-looking update (csrc/pta_td_fused.hip).  A = the factor buffer (contents ignored), even order / pitch / stride.
+extern "C" int pta_td_assemble_potrf(const double *Fr, const double *Gr, int kf, const double *sigma2, const int32_t *epoch_of, const double *ecorr2,
+                                     double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,
+                                     int64_t work_doubles, void *stream) {
+  PTA_REQUIRE(Fr && Gr && sigma2 && (!epoch_of || ecorr2), PTA_E_ARG, "pta_td_assemble_potrf: NULL argument");
+  PTA_REQUIRE(kf >= 0 && kf <= 64 && n > 0 && !(n & 1) && !(lda & 1) && !(strideA & 1), PTA_E_ARG,
+              "pta_td_assemble_potrf: kf=%d n=%d lda=%lld strideA=%lld (kf <= 64; even order, pitch and stride)", kf, n, (long long)lda, (long long)strideA);
+  pta_fuse fz{Fr, Gr, sigma2, epoch_of, epoch_of ? ecorr2 : nullptr, (int64_t)n, kf};
+  return pta_potrf_impl(A, n, lda, strideA, B, info, flags | PTA_POTRF_LEFT, work, work_doubles, stream, &fz);
 }
 
 extern "C" int pta_potrf_batched_ws(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, double *work,

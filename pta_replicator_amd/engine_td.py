@@ -86,8 +86,11 @@ class TimeDomainMixin:
         # an unexplained NaN observation; its cause was an out-of-range operand read of the withdrawn assembly kernel (DESIGN.md §4.2,
         # csrc/pta_td_kernels.hip), not an ordering hazard, and tests/test_gpu_td.py::test_td_prepare_without_host_sync_* hold the
         # asynchronous sequence bit-equal to a fully serialised one.
-        self.td_assemble()
-        self.td_factorise(lookahead=lookahead)
+        if self._td_can_fuse(lookahead):
+            self.td_assemble_factorise()                  # uniform array: the assembly fused into the left-looking factorisation's updates
+        else:
+            self.td_assemble()
+            self.td_factorise(lookahead=lookahead)
         blk, n0, rows = _strips(counts)
         self._td_keep = self._td_layout + [dv.i32(blk), dv.i32(n0), dv.i32(rows)]
         tp = _lib.TdPlan()
@@ -107,6 +110,53 @@ class TimeDomainMixin:
         self._td_bufs = None
         self._td_prepared = True
         return self
+
+    def _td_can_fuse(self, lookahead=True):
+        """the fused assembly + factorisation (pta_td_assemble_potrf; OPT-IN: attribute td_fused = True) applies to what the headline array
+        is: every pulsar the same EVEN TOA count above one panel, <= 64 red-noise columns, the default left-looking order with its workspace,
+        no A/B flags.  Not the default because it is a wash: at 68 x 5000^2 its update launches take 33.25 ms against 31.22 + 1.98 for the
+        plain updates + k_td_cov_walk (one chain, rocprofv3: scripts/gpu_r6_fused_trace.py), prepare_td() 54.2 against 54.7 ms - the K = 60
+        product it moves into the updates is 109 GFLOP that the walking kernel already runs beside its HBM writes, and the C read it
+        saves was hidden behind the products (DESIGN.md §4.2)."""
+        nst = self.td_nst
+        return (bool(getattr(self, "td_fused", False)) and lookahead and len(set(nst)) == 1 and all(int(c) % 2 == 0 for c in self.counts)
+                and nst[0] > 1152 and nst[0] < 16384 and self.plan.rn_k <= 64 and getattr(self, "td_potrf_mode", "auto") in ("auto", "uniform")
+                and getattr(self, "td_potrf_order", "left") == "left" and bool(getattr(self, "td_potrf_workspace", True))
+                and int(getattr(self, "td_potrf_flags", 0)) == 0 and getattr(self, "td_cov_kernel", "auto") == "auto")
+
+    def td_assemble_factorise(self):
+        """covariance assembly AND batched factorisation of a uniform array as ONE call: the covariances are never written - every block
+        column of the left-looking factorisation is computed by its update, F diag(phi) F^T + diag(sigma^2) + ECORR - L L^T, from row-major
+        copies of the design matrix (Fr, and Gr = -phi Fr: 2 x 64 columns x 8 bytes per TOA, built once per noise model).  Saves the
+        assembly launch and the 2 x 8 bytes per element of round trip (VERDICT r5 #5); the factors agree with the two-step path to rounding."""
+        P, N, K, s = self.P, self.n_toa, self.plan.rn_k, dv.stream_ptr()
+        key = (self.d_Ft.data_ptr() if K else 0, self.d_amp.data_ptr() if K else 0)
+        op = getattr(self, "_td_fuse_ops", None)
+        if op is None or op[0] != key:
+            if K:
+                Fr = dv.zeros((N, 64))
+                Fr[:, :K] = self.d_Ft.t()
+                phi = (self.d_amp ** 2)[self.d_psr_of.long()]                 # [N, K]: each TOA's pulsar's prior variances
+                Gr = dv.zeros((N, 64))
+                Gr[:, :K] = -(phi * Fr[:, :K])
+            else:
+                Fr = Gr = dv.zeros((64,))                                     # kf = 0: never read
+            op = self._td_fuse_ops = (key, Fr, Gr)
+        ecorr2 = (self.d_ecorr_toa ** 2).contiguous() if self.plan.ecorr_toa else None
+        n, ld = self.td_nst[0], self.td_ld[0]
+        info = dv.zeros((P,), dtype=torch.int32)
+        flags = _lib.POTRF_LEFT
+        need = int(_lib.lib.pta_potrf_workspace_doubles(n, P, flags))
+        work = dv.empty((need,))
+        _lib.call("pta_td_assemble_potrf", dv.ptr(op[1]), dv.ptr(op[2]), K, dv.ptr(self._td_sigma2),
+                  dv.ptr(self.d_epoch_of) if ecorr2 is not None else None, dv.ptr(ecorr2) if ecorr2 is not None else None,
+                  dv.ptr(self.d_Ltd), n, ld, n * ld, P, dv.ptr(info), flags, dv.ptr(work), need, s)
+        del work
+        self.td_cov_kernel_used, self.td_potrf_mode_used = "fused", "uniform"
+        bad = info.cpu().numpy()
+        if np.any(bad != 0):
+            a = int(np.nonzero(bad)[0][0])
+            raise np.linalg.LinAlgError(f"TD covariance of {self.names[a]} is not positive definite (leading minor {int(bad[a])})")
 
     def td_assemble(self, kernel=None):
         """ONE assembly launch over all pulsars: lower triangles of C_a into the factor buffer (+ the identity tail of odd orders).

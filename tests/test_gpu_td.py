@@ -316,6 +316,59 @@ def test_td_and_throughput_mode_have_the_same_ensemble_covariance():
     assert abs(np.trace(c_td) / np.trace(c_fd) - 1) < 0.03
 
 
+@pytest.mark.parametrize("P,N,unsorted", [(5, 2600, False), (3, 1410, True), (2, 5000, False)])
+def test_td_fused_assembly_factorisation_equals_two_step(P, N, unsorted):
+    """round 6: pta_td_assemble_potrf - the covariance never written, every block column of the left-looking factorisation
+    COMPUTED by its update (F phi F^T + diag + ECORR - L L^T) - against the two-step path (k_td_cov_walk, then pta_potrf_batched_ws in the
+    same panel order) on the ng15 noise values: per-backend EFAC / EQUAD / ECORR, a pulsar without red noise, 2 / 3 / 5 pulsars (chains
+    of unequal size: the assembly operands are offset per chain), 2 - 5 panels, TOAs in time order and shuffled (ECORR epochs scattered
+    over the tiles).  Factors within 1e-12 of each other relative to max |L| (the K = 60 product is summed in another order) and within
+    1e-10 of LAPACK on the oracle's covariance; L.z on the dumped deviates at 1e-10; the fused path is deterministic (bit-equal reruns)."""
+    import torch
+    from pta_replicator_amd.engine import ReplicaEngine
+    from bench import configure_engine, headline_array
+    psrs, noise = headline_array(P, N, seed=70 + P)
+    if unsorted:
+        from pta_replicator_amd.simulate import ArrayTOAs, SimulatedPulsar, make_ideal
+        rng = np.random.default_rng(3)
+        sh = []
+        for p in psrs:
+            perm = rng.permutation(N)
+            q = SimulatedPulsar(toas=ArrayTOAs(np.asarray(p.toas.get_mjds().value)[perm], 0.5, flags=[p.toas.flags[i] for i in perm]), name=p.name, loc=dict(p.loc))
+            make_ideal(q)
+            sh.append(q)
+        psrs = sh
+    noise["rn_log10_A"][1], noise["rn_gamma"][1] = None, None        # one pulsar without red noise
+    eng = configure_engine(ReplicaEngine(psrs, seed=5), noise)
+    eng._gw = None
+    eng.prepare()
+    eng.td_fused = False
+    eng.prepare_td()
+    assert eng.td_cov_kernel_used == "walk"
+    two = [eng.td_factor(a).cpu().numpy() for a in range(P)]
+    eng.td_fused = True
+    eng.d_Ltd.fill_(float("nan"))                                     # the fused path reads nothing of the buffer
+    eng.prepare_td()
+    assert eng.td_cov_kernel_used == "fused" and eng.td_potrf_mode_used == "uniform"
+    fused = [eng.td_factor(a).cpu().numpy() for a in range(P)]
+    first = eng.d_Ltd.clone()
+    for a in range(P):
+        assert np.all(np.isfinite(fused[a]))
+        assert np.max(np.abs(fused[a] - two[a])) < 1e-12 * np.max(np.abs(two[a])), a
+    covs = _oracle_covariances(eng, psrs, noise, components=30)
+    for a in (0, 1):
+        Lref = np.linalg.cholesky(covs[a])
+        assert np.max(np.abs(fused[a] - Lref)) < 1e-10 * np.max(np.abs(Lref)), a
+    out = eng.generate_td(2).cpu().numpy()
+    for a in (0, 1):
+        z = eng.dump_draws_td(1)["td"][a]
+        assert relrms(out[1, eng.off[a]:eng.off[a + 1]], np.linalg.cholesky(covs[a]) @ z) < 1e-10
+    eng.prepare_td()
+    lower = torch.tril(torch.ones((eng.td_nst[0], eng.td_ld[0]), dtype=torch.bool, device="cuda"))
+    v0, v1 = first.view(P, eng.td_nst[0], eng.td_ld[0]), eng.d_Ltd.view(P, eng.td_nst[0], eng.td_ld[0])
+    assert bool(torch.equal(v0[:, lower], v1[:, lower]))
+
+
 def test_td_headline_size_vs_numpy():
     """N = 5000 TOAs, two pulsars with the ng15 noise values of config 3: covariance, factor and L.z against NumPy / LAPACK at
     1e-10 (the size BASELINE.json's metric is quoted on; LAPACK's potrf of a 5000^2 takes about a second)."""
