@@ -668,6 +668,10 @@ int pta_dgemm_launch_rag(int M, int N, int K, double alpha, double *Abase, int r
       const unsigned nt = pta_cdiv(M, HBM_T);
       g = dim3(nt * (nt + 1) / 2, 1, batch);
       lower_only = 2;
+    } else if (lower_only && M > N) {  // trapezoid (a block column): 1-D grid over its live tiles, dealt evenly to the XCDs (see the kernel)
+      const unsigned nt = pta_cdiv(N, HBM_T), mt = pta_cdiv(M, HBM_T);
+      g = dim3(nt * (nt + 1) / 2 + (mt - nt) * nt, 1, batch);
+      lower_only = 2;
     }
     auto kern = rg.epi ? k_dgemm_glds128<true, 1> : k_dgemm_glds128<true, 0>;
     hipLaunchKernelGGL(kern, g, dim3(256), 0, stream, M, N, K, alpha, Abase, (int64_t)0, B, ldb, beta, Abase, (int64_t)0, lower_only,

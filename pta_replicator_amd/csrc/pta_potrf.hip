@@ -1301,6 +1301,24 @@ static int pta_rag_chain_run(const pta_rag_chain &c, hipStream_t s, hipStream_t 
   return rc;
 }
 
+// The same chain in LEFT-LOOKING order (PTA_POTRF_LEFT in the plan's flags; round 6, as pta_potrf_chain_ws_left for uniform batches): no
+// trailing updates - before the panel of time step Tq is factored, its block column (virtual rows [kq, E), the panel's NBO columns) is
+// updated ONCE with every virtual column to its left, K = kq: one masked tile product over the matrices active at Tq (a matrix's K loop
+// starts at the slab that holds its front; one that enters at this step has nothing to its left and leaves at once).  No look-ahead.
+static int pta_rag_chain_run_left(const pta_rag_chain &c, hipStream_t s) {
+  int T = c.Tmax, B = pta_rag_active(c, T);
+  int rc = pta_rag_diag_phase(c, T, B, s);
+  while (rc == PTA_OK && T > 0) {
+    if ((rc = pta_rag_solve_phase(c, T, B, s)) != PTA_OK) break;
+    const int Tq = T - 1, Bq = pta_rag_active(c, Tq), kq = c.E - c.NBO * (Tq + 1);
+    if ((rc = pta_dgemm_launch_rag(c.E - kq, c.NBO, kq, -1.0, c.A, kq, kq, 0, nullptr, 0, 0, 1.0, 1, Bq, c.rg, s)) != PTA_OK) break;
+    rc = pta_rag_diag_phase(c, Tq, Bq, s);
+    T = Tq;
+    B = Bq;
+  }
+  return rc;
+}
+
 extern "C" int64_t pta_potrf_ragged_plan_words(int B) { return B > 0 ? PTA_RAG_HDR + PTA_RAG_CHDR * PTA_POTRF_MAX_CHAINS + 5 * (int64_t)B : 0; }
 
 extern "C" int pta_potrf_ragged_plan(const int32_t *n, const int64_t *off, const int64_t *ld, int B, int flags, int64_t *plan, int64_t *work_doubles) {
@@ -1418,7 +1436,7 @@ extern "C" int pta_potrf_ragged(double *A, const int64_t *plan, const int64_t *p
       rc_chain = PTA_E_HIP;
       break;
     }
-    rc_chain = pta_rag_chain_run(ch, sc, la ? cx->side[c] : nullptr, cx->ev_u1[c], cx->ev_la[c]);
+    rc_chain = (flags & PTA_POTRF_LEFT) ? pta_rag_chain_run_left(ch, sc) : pta_rag_chain_run(ch, sc, la ? cx->side[c] : nullptr, cx->ev_u1[c], cx->ev_la[c]);
   }
   if (nchain > 1)
     for (int c = 0; c < nchain; ++c) {  // join on every exit, error included
