@@ -317,6 +317,13 @@ def _spd(rng, n):
     ((5000,), 0),                                                           # a batch of one
     ((778, 90, 1026, 2602), 0),                                             # the TD test array's orders (cuts 10 / 2 / 90 columns wide)
     ((2500, 130, 1024, 1026, 3000, 64, 2, 1152, 2048, 900), "EPI1"),       # tile products with the C-tile prefetch epilogue (A/B form)
+    # left-looking order (round 6): every time step's block column updated once with all virtual columns to its left
+    ((1500, 258, 700, 256, 254, 1280, 1282, 66, 1024, 512, 130), "NB1LEFTC3"),
+    ((4200, 3100, 600, 2050), "LEFT"),
+    ((4200, 3100, 600, 2050, 4200, 3098), "NB2LEFT"),
+    ((2200, 2200, 2200), "NB1LEFT"),
+    ((778, 90, 1026, 2602), "LEFT"),
+    ((5000,), "LEFT"),
 ])
 def test_potrf_ragged_vs_numpy(gpu, orders, flags):
     """pta_potrf_ragged: matrices of different orders as ONE end-aligned schedule (red_noise.py:286-298 loops pulsars; a real array has
@@ -325,7 +332,8 @@ def test_potrf_ragged_vs_numpy(gpu, orders, flags):
     matrices smaller than one block."""
     lib = gpu["lib"]
     fl = {0: 0, "C1": lib.POTRF_CHAINS(1), "NOLA": lib.POTRF_NO_LOOKAHEAD, "NB1": lib.POTRF_NB(1), "NB1C3": lib.POTRF_NB(1) | lib.POTRF_CHAINS(3),
-          "NB2": lib.POTRF_NB(2), "NB8": lib.POTRF_NB(8), "EPI1": lib.POTRF_EPI1}[flags]
+          "NB2": lib.POTRF_NB(2), "NB8": lib.POTRF_NB(8), "EPI1": lib.POTRF_EPI1, "LEFT": lib.POTRF_LEFT, "NB1LEFT": lib.POTRF_NB(1) | lib.POTRF_LEFT,
+          "NB2LEFT": lib.POTRF_NB(2) | lib.POTRF_LEFT, "NB1LEFTC3": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_CHAINS(3)}[flags]
     rng = np.random.default_rng(sum(orders))
     mats = [_spd(rng, n) for n in orders]
     Ls, info = _ragged_factor(gpu, mats, fl)
