@@ -99,7 +99,10 @@ def td_mode_numbers(eng, R):
     # fresh memory, ~0.2-0.4 s, paid once per process - the caching allocator hands the block back on later calls): timed on its own,
     # then prepare_td() twice - the first call still creates the internal streams / events and the GWB grid factor
     counts = [int(c) for c in eng.counts]
-    nbytes = 8 * sum(n * (n + (n & 1)) for n in counts)
+    # exactly the buffer prepare_td() asks for (orders padded to even, row pitches to 16 doubles: engine_td.prepare_td) - rounds 3-5 sized this
+    # block by n x n, 0.16 % SMALLER than the factor buffer, so the caching allocator could not hand it back and the "first call" figure
+    # silently contained a fresh 13.6 GB hipMalloc: the 94 ... 249 ms spread between boxes was the driver's allocation time
+    nbytes = 8 * sum((n + (n & 1)) * ((n + (n & 1) + 15) // 16 * 16) for n in counts) + (4 << 20)   # + slack: a cached block serves any smaller request
     torch.cuda.synchronize(); t0 = time.perf_counter()
     blk = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize(); t_alloc = time.perf_counter() - t0
