@@ -1023,8 +1023,7 @@ static int pta_potrf_chain_ws_left(double *A, int n, int64_t lda, int64_t stride
     double *C = A + (int64_t)q.k0 * lda + q.k0;
     return pta_dgemm_launch(1, n - q.k0, q.nbo, kb - ka, -1.0, Lr, lda, 1, Lr, lda, 1.0, C, lda, 1, B, strideA, strideA, strideA, algo, st);
   };
-  bool ua_pending = false;  // a U_a product is in flight on `side` (its completion = ev_ua)
-  int prev_k0 = 0;          // first column of panel p - 1 ... tracked as: U_a(q) covers [0, p.k0), U_b(q) covers [p.k0, q.k0)
+  bool ua_pending = false;  // a U_a product is in flight on `side` (its completion = ev_ua): U_a(q) covers [0, p.k0), U_b(q) covers [p.k0, q.k0)
   while (p.rows > 0) {
     if ((rc = pta_ws_solve_phase(A, lda, strideA, B, algo, p, W, ldw, sW, s)) != PTA_OK) break;
     const pta_ws_panel q = pta_ws_panel_at(n, NBO, p.pend);  // the next panel
@@ -1049,10 +1048,8 @@ static int pta_potrf_chain_ws_left(double *A, int n, int64_t lda, int64_t stride
       break;
     }
     if ((rc = pta_ws_diag_phase(A, lda, strideA, B, info, flags, algo, q, W, ldw, sW, s)) != PTA_OK) break;
-    prev_k0 = p.k0;
     p = q;
   }
-  (void)prev_k0;
   if (ua_pending) (void)hipStreamWaitEvent(s, ev_ua, 0);  // error exit: the chain's stream never runs ahead of its side stream
   return rc;
 }
@@ -1078,8 +1075,10 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default
-  // default: two chains (with PTA_POTRF_DIAG_AHEAD and the 128-column base case: 53.2 ms against 54.1 with one chain, 58.3 with three)
-  if (nchain == 0) nchain = 2;
+  // default: two chains (with PTA_POTRF_DIAG_AHEAD and the 128-column base case: 53.2 ms against 54.1 with one chain, 58.3 with three) - from
+  // eight matrices up; a handful of matrices is one chain (3 x 10 000^2, round 6: 29.1-30.7 ms against 33.6-34.4 with two: each chain's
+  // launches would fill a fraction of the chip and the chains only delay each other)
+  if (nchain == 0) nchain = B >= 8 ? 2 : 1;
   if (nchain > PTA_POTRF_MAX_CHAINS) nchain = PTA_POTRF_MAX_CHAINS;
   if (nchain > B) nchain = B;
   if ((flags & PTA_POTRF_NO_LOOKAHEAD) || !algo || n <= NBO) nchain = 1;

@@ -100,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void k_td_fused_update(int M, int N, int K,
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = pta_f64x4{0.0, 0.0, 0.0, 0.0};
-  // one slab: 16 fragment reads, 64 MFMAs; `sgn` = -1 for the factor phase (acc = F phi F^T - L L^T needs no second accumulator set: the
-  // design-matrix operand Gr carries -phi, the epilogue negates).  `next` issues the DMA of the following slab behind the first 16 products.
+  // one slab: 16 fragment reads, 64 MFMAs.  Both phases add into the SAME accumulators: the design-matrix operand Gr carries -phi, so
+  // acc = L L^T - F phi F^T and the epilogue stores -acc.  `next` issues the DMA of the following slab behind the first 16 products.
   auto slab_product = [&](int cur, int kv, auto next) {
     const char *pa = reinterpret_cast<const char *>(&slab[cur][0][0]) + offA;
     const char *pb = reinterpret_cast<const char *>(&slab[cur][1][0]) + offB;
