@@ -1341,7 +1341,9 @@ extern "C" int pta_potrf_ragged_plan(const int32_t *n, const int64_t *off, const
       s3 += x * x * x;
       s4 += x * x * x * x;
     }
-    nbk = (s4 >= 16384.0 * s3) ? 8 : 4;
+    // ... from six matrices up: a handful of large matrices keeps 1024 columns (round 6, scripts/gpu_r6_run15.sh: config 2's three
+    // matrices 0.709 against 0.698 of peak, 3 x 20 000^2 0.684 against 0.671; 12 large matrices 0.824 against 0.835, 24: 0.794 / 0.805)
+    nbk = (s4 >= 16384.0 * s3 && B >= 6) ? 8 : 4;
   }
   const int NBO = nbk * 4 * CH_NB;
   int nchain = (flags >> 16) & 0xF;

@@ -489,7 +489,14 @@ def test_ragged_cholesky_plan_is_end_aligned_and_sorted():
         _lib.call("pta_potrf_ragged_plan", n.ctypes.data, off.ctypes.data, ld.ctypes.data, B, flags, plan.ctypes.data, ctypes.byref(need))
         return plan, need.value
 
-    # (the default panel is 2048 columns here: the flop-weighted mean order of these six matrices is 35 000; 1024 below 16 384)
+    # (the default panel is 2048 columns here: the flop-weighted mean order of these six matrices is 35 000; 1024 below 16 384 - and
+    # for fewer than six matrices whatever their orders: round 6, BASELINE config 2's three matrices)
+    n3 = np.array([7758, 23024, 35038], dtype=np.int32)
+    ld3 = ((n3 + 15) // 16 * 16).astype(np.int64)
+    off3 = np.concatenate([[0], np.cumsum(n3.astype(np.int64) * ld3)])[:-1].astype(np.int64)
+    plan3 = np.zeros(int(_lib.lib.pta_potrf_ragged_plan_words(3)), dtype=np.int64)
+    _lib.call("pta_potrf_ragged_plan", n3.ctypes.data, off3.ctypes.data, ld3.ctypes.data, 3, 0, plan3.ctypes.data, ctypes.byref(ctypes.c_int64(0)))
+    assert plan3[4] == 1024 and plan3[3] == 2
     for flags, nchain, NB in ((0, 2, 2048), (_lib.POTRF_CHAINS(3) | _lib.POTRF_NB(1), 3, 256), (_lib.POTRF_NO_LOOKAHEAD | _lib.POTRF_NB(4), 1, 1024)):
         plan, need = plan_for(flags)
         assert plan[1] == B and plan[3] == nchain and plan[4] == NB and plan[5] == need == B * NB * NB
