@@ -184,6 +184,9 @@ int pta_potrf_batched(double *A, int n, int B, int32_t *info, void *stream);
                                      * product of K = the panel's first column: a C tile is read and written once, not once per panel) */
 #define PTA_POTRF_LEFT_SPLIT 0x400000 /* with PTA_POTRF_LEFT: the part of that update that only needs panels <= q - 2 runs ahead on an internal
                                        * side stream beside panel q - 1's diagonal phase and substitution */
+#define PTA_POTRF_SOLVE_ROWS 0x800000 /* workspace scheme (ABI 8): the substitution on the rows below a panel as ONE launch - a workgroup keeps a
+                                       * 128-row tile and walks the panel's 128-column blocks (reading back its own stores through L2: sc1 loads)
+                                       * instead of one launch per block */
 int pta_potrf_batched_ex(double *A, int n, int64_t lda, int64_t strideA, int B, int32_t *info, int flags, void *stream);
 
 /* The same factorisation with a caller-owned workspace (device memory, `work_doubles` doubles, at least

@@ -127,7 +127,7 @@ ENGINE_EPMAX = 132  # PTA_ENGINE_EPMAX
 TD_STRIP = 256      # PTA_TD_STRIP
 POTRF_ZERO_UPPER, POTRF_NO_LOOKAHEAD, POTRF_SUBSTITUTION, POTRF_VALU, POTRF_REG_STAGING, POTRF_LOCKSTEP, POTRF_DIAG_AHEAD, POTRF_DIAG64 = 1, 2, 4, 8, 32, 64, 128, 16
 POTRF_EPI1 = 0x100000
-POTRF_LEFT, POTRF_LEFT_SPLIT = 0x200000, 0x400000
+POTRF_LEFT, POTRF_LEFT_SPLIT, POTRF_SOLVE_ROWS = 0x200000, 0x400000, 0x800000
 
 
 def POTRF_CHAINS(c):

@@ -75,3 +75,7 @@ struct pta_fuse {
   int32_t kf;             // red-noise columns in use (0 = none: the design-matrix phase is skipped)
 };
 int pta_td_fused_launch(int M, int N, int K, double *L, int64_t ld, int64_t sL, int r0, int batch, const pta_fuse &fz, hipStream_t stream);
+
+// blocked substitution of a whole panel in one launch, a workgroup per 128-row tile walking the panel's blocks (csrc/pta_solve_rows.hip)
+int pta_ws_solve_rows_launch(double *X, int64_t lda, int64_t sA, int B, int rows, int nb, int f128, const double *W, int64_t ldw, int64_t sW,
+                             hipStream_t stream);

@@ -875,6 +875,11 @@ static int pta_ws_diag_phase(double *A, int64_t lda, int64_t strideA, int B, int
 static int pta_ws_solve_phase(double *A, int64_t lda, int64_t strideA, int B, int algo, const pta_ws_panel &p, double *W, int64_t ldw, int64_t sW,
                               hipStream_t s) {
   double *Bp = A + (int64_t)p.pend * lda + p.k0;
+  // algo 4 (PTA_POTRF_SOLVE_ROWS): the panel's blocks in ONE launch, a workgroup per 128-row tile walking them (csrc/pta_solve_rows.hip);
+  // needs the 16-byte operand alignment of the DMA kernels (even offsets and pitches) and at least one whole tile of rows
+  if (algo == 4 && p.rows >= 128 && !(p.f128 & 1) && !(p.k0 & 1) && !(lda & 1) && !(strideA & 1) && !(ldw & 1) && !(sW & 1) && ((uintptr_t)A % 16) == 0 &&
+      ((uintptr_t)W % 16) == 0)
+    return pta_ws_solve_rows_launch(Bp, lda, strideA, B, p.rows, p.nb, p.f128, W, ldw, sW, s);
   for (int j = 0; j < p.nb; ++j) {
     const int oj = j == 0 ? 0 : p.f128 + 128 * (j - 1), wj = j == 0 ? p.f128 : 128;
     int rc = pta_ws_apply_block(Bp + oj, lda, strideA, B, p.rows, wj, oj, W + (int64_t)j * 128 * ldw, ldw, sW, algo, s);
@@ -1071,7 +1076,7 @@ static int pta_potrf_impl(double *A, int n, int64_t lda, int64_t strideA, int B,
   // 0: VALU reference GEMM + substitution panel solve (cross-check); 2 (default): MFMA kernels, the 128 x 128-tile products' operand
   // slabs brought in by LDS DMA (k_dgemm_glds128: 66 against 59 TFLOP/s at K = 1024, the whole 68 x 5000^2 batch 56.4 against 60.0
   // ms); 1 (PTA_POTRF_REG_STAGING): the same products with register-staged slabs (round 2's kernel, kept for the A/B)
-  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_REG_STAGING) ? 1 : ((flags & PTA_POTRF_EPI1) ? 3 : 2));
+  const int algo = (flags & PTA_POTRF_VALU) ? 0 : ((flags & PTA_POTRF_REG_STAGING) ? 1 : ((flags & PTA_POTRF_EPI1) ? 3 : ((flags & PTA_POTRF_SOLVE_ROWS) ? 4 : 2)));
   const int nbk = (flags >> 8) & 0xFF;
   const int NBO = (nbk ? nbk : 4) * 4 * CH_NB;      // panel width: 1024 columns unless overridden (PTA_POTRF_NB)
   int nchain = (flags >> 16) & 0xF;                  // PTA_POTRF_CHAINS; 0 = default

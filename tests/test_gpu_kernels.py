@@ -229,7 +229,11 @@ def test_potrf_batched_vs_numpy(gpu, n, batch):
                                            (3000, 2, "LEFT"), (3000, 2, "LEFTS"), (4200, 3, "LEFTS"), (2500, 2, "NB1LEFT"), (2900, 3, "NB1LEFTSC3"), (2501, 2, "NB1LEFTS"),
                                            (1200, 3, "LEFTS"), (4300, 1, "NB2LEFTS1"),
                                            # left-looking with the diagonal phases run ahead on the high-priority side stream (U_top / U_rest)
-                                           (3000, 2, "LEFTLA"), (4200, 3, "LEFTLA"), (2900, 3, "NB1LEFTLAC3"), (2501, 2, "NB1LEFTLA"), (1200, 3, "LEFTLA"), (4300, 1, "NB2LEFTLA1")])
+                                           (3000, 2, "LEFTLA"), (4200, 3, "LEFTLA"), (2900, 3, "NB1LEFTLAC3"), (2501, 2, "NB1LEFTLA"), (1200, 3, "LEFTLA"), (4300, 1, "NB2LEFTLA1"),
+                                           # the substitution as ONE launch per panel (a workgroup per 128-row tile walks the panel's blocks, reading back its own
+                                           # stores through L2): left- and right-looking, narrow first blocks (n mod 128 = 8, 56, 104), an odd order (falls back)
+                                           (3000, 2, "LEFTROWS"), (4200, 9, "LEFTROWS"), (5000, 3, "LEFTROWS"), (2900, 3, "NB1LEFTROWSC3"), (2501, 2, "NB1LEFTROWS"),
+                                           (4200, 3, "LAROWS"), (4328, 2, "NB2LEFTROWS"), (1290, 2, "LEFTROWS")])
 def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     """pta_potrf_batched_ws: panels factored on their diagonal block, explicit inverse W = L11^-1 in a caller-owned workspace (handed
     over full of NaN), rows below solved as X = B W^T right to left - against LAPACK, with leading dimension / stride slack, odd
@@ -247,7 +251,10 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
           "NB2LEFTS1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_LEFT_SPLIT | lib.POTRF_CHAINS(1),
           "LEFTLA": lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD, "NB1LEFTLA": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD,
           "NB1LEFTLAC3": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(3),
-          "NB2LEFTLA1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(1)}[flags]
+          "NB2LEFTLA1": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_DIAG_AHEAD | lib.POTRF_CHAINS(1),
+          "LEFTROWS": lib.POTRF_LEFT | lib.POTRF_SOLVE_ROWS, "NB1LEFTROWS": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_SOLVE_ROWS,
+          "NB1LEFTROWSC3": lib.POTRF_NB(1) | lib.POTRF_LEFT | lib.POTRF_SOLVE_ROWS | lib.POTRF_CHAINS(3),
+          "NB2LEFTROWS": lib.POTRF_NB(2) | lib.POTRF_LEFT | lib.POTRF_SOLVE_ROWS, "LAROWS": lib.POTRF_DIAG_AHEAD | lib.POTRF_SOLVE_ROWS}[flags]
     rng = np.random.default_rng(n + batch)
     X = rng.standard_normal((batch, n, n + 5))
     A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
