@@ -281,6 +281,43 @@ def test_potrf_workspace_scheme_vs_numpy(gpu, n, batch, flags):
     assert int(lib.lib.pta_potrf_workspace_doubles(n, batch, fl | lib.POTRF_SUBSTITUTION)) == 0
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_potrf_uniform_schedules_random_shapes(gpu, seed):
+    """round 6: random uniform batches (1 ... 11 matrices, orders 1025 ... 4500 - even and odd, any n mod 128 -, leading-dimension and stride
+    slack, NaN above the diagonals, NaN workspace) under a random choice among the schedules of the workspace scheme - left-looking
+    (the engine's default), left-looking with the run-ahead split / run-ahead diagonal phases / row-resident substitution, right-looking with
+    look-ahead, 256 ... 2048-column panels, 1 ... 4 chains: every factor against LAPACK, and a second run bit-identical to the first."""
+    dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
+    rng = np.random.default_rng(6000 + seed)
+    n = int(rng.integers(1025, 4501))
+    if seed % 2 == 0:
+        n += n & 1                                                     # the DMA kernels' path (even order); odd orders take the scalar-operand kernels
+    B = int(rng.integers(1, 12))
+    L, S, LA, RW = lib.POTRF_LEFT, lib.POTRF_LEFT_SPLIT, lib.POTRF_DIAG_AHEAD, lib.POTRF_SOLVE_ROWS
+    sched = [L, L | S, L | LA, L | RW, LA, L | RW | LA, LA | RW, L, L | S, L | RW][seed]
+    fl = sched | lib.POTRF_NB(int(rng.choice([1, 2, 3, 4, 4, 6, 8]))) | lib.POTRF_CHAINS(int(rng.integers(1, 5)))
+    X = rng.standard_normal((B, n, n + 3))
+    A = X @ X.transpose(0, 2, 1) + 0.1 * np.eye(n)
+    ld = n + (n & 1) + 2 * int(rng.integers(0, 3))
+    rows = n + int(rng.integers(0, 2))
+    buf = np.full((B, rows, ld), np.nan)
+    buf[:, :n, :n] = np.tril(A) + np.triu(np.full((n, n), np.nan), 1)
+    need = int(lib.lib.pta_potrf_workspace_doubles(n, B, fl))
+    outs = []
+    for rep in range(2):
+        Ad = dv.f64(buf)
+        info = dv.zeros((B,), dtype=torch.int32)
+        work = dv.empty((max(need, 1),))
+        work.fill_(float("nan"))
+        lib.call("pta_potrf_batched_ws", dv.ptr(Ad), n, ld, rows * ld, B, dv.ptr(info), fl, dv.ptr(work) if need else None, need, gpu["s"])
+        assert int(info.abs().sum().item()) == 0, (n, B, hex(fl))
+        outs.append(np.tril(Ad.cpu().numpy()[:, :n, :n]))
+    ref = np.linalg.cholesky(A)
+    assert np.all(np.isfinite(outs[0]))
+    assert np.max(np.abs(outs[0] - ref)) < 1e-10 * np.max(np.abs(ref)), (n, B, hex(fl))
+    assert np.array_equal(outs[0], outs[1]), (n, B, hex(fl))
+
+
 def _ragged_factor(gpu, mats, flags, nan_upper=True):
     """pta_potrf_ragged on a list of SPD matrices (any even orders): returns the lower factors and info."""
     dv, lib, torch = gpu["dv"], gpu["lib"], gpu["torch"]
